@@ -1,0 +1,69 @@
+// Device-side layout of an engine's workspace, shared by the kernels and the host API.
+#pragma once
+#include <stdint.h>
+#include "../../include/nnb.h"
+
+namespace nnb {
+
+typedef unsigned long long u64;
+
+// One MCTS node, 16 bytes so a child is one 128-bit load.  Children of a node are
+// allocated contiguously in ascending column order (mcts.py:35-38 iterates
+// legal_moves, which connect_four_game.py:115 builds ascending), so a node only
+// stores the index of its first child and how many it has.
+struct __attribute__((aligned(16))) Node {
+    double   value;        // accumulated backup value (MCTSNode.value, mcts.py:20)
+    int32_t  visits;       // MCTSNode.visits (mcts.py:19)
+    uint16_t first_child;  // index of the first child in this game's pool
+    uint8_t  nchild;       // 0 = leaf (MCTSNode.is_leaf, mcts.py:22-23)
+    uint8_t  action;       // column that leads here (MCTSNode.action)
+};
+static_assert(sizeof(Node) == 16, "Node must be 16 bytes");
+
+constexpr int kPathSlots = 64;      // one path entry per lane; depth <= 42
+constexpr int kMaxPlies = 42;
+
+// Pointers into the workspace (all device memory).  G = max_games.
+struct EngineDev {
+    int32_t  max_games;
+    int32_t  pool_cap;          // nodes per game = 1 + 7*max_sims
+    int32_t  max_sims;
+    int32_t  n_games;           // games / roots in the current call
+
+    Node    *nodes;             // [G][pool_cap]
+    float   *prior;             // [G][pool_cap]   (AZ mode only)
+    double  *log_table;         // [max_sims + 8]  log(n + 1), filled by the host's libm
+
+    u64     *root_boards;       // [G][2] colour boards of each root
+    int8_t  *root_player;       // [G]
+    int32_t *active;            // [G] 1 while the game / search is live
+    int32_t *n_nodes;           // [G]
+    int32_t *sims_done;         // [G]
+    int32_t *pending;           // [G] leaf-batch slot awaiting its value, -1 = none
+    int32_t *path_len;          // [G]
+    uint16_t *path;             // [G][kPathSlots] node indices root -> leaf of the pending leaf
+    int32_t *ply;               // [G] plies played (self-play)
+    int32_t *game_stats;        // [G][4]: depth_sum, terminal_hits, net_leaves, sims
+
+    u64     *leaf_side;         // [G][2] side boards (me, opp) of the compacted leaf batch
+    uint8_t *leaf_legal;        // [G]    legal mask of each batched leaf
+    int32_t *leaf_count;        // [2]    ring of batch sizes, indexed by step parity
+    float   *leaf_value;        // [G]    network / evaluator value per batch slot
+    float   *leaf_logp;         // [G][7] network log-policy per batch slot
+    float   *leaf_prior;        // [G][7] masked, renormalised priors per batch slot
+    int32_t *counters;          // [16]   [0] = live games after the last readout
+    unsigned long long *stats64; // [8]   depth, terminal hits, leaves, sims, plies (stats_reduce_kernel)
+};
+
+struct SearchDev {
+    int32_t mode;
+    int32_t evaluator;
+    int32_t sims;
+    int32_t flags;
+    double  c_puct;
+    double  dirichlet_alpha;
+    double  dirichlet_eps;
+    u64     seed;
+};
+
+}  // namespace nnb

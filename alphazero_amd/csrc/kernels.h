@@ -1,0 +1,56 @@
+// Host-callable launchers of the engine's kernels (each defined next to its kernel).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "engine_layout.h"
+
+namespace nnb {
+
+// tree_kernels.hip
+void launch_game_ops(hipStream_t st, int n, const u64 *in, const int8_t *players, const int8_t *actions,
+                     u64 *out, uint8_t *legal_out, uint8_t *status_out);
+void launch_encode_planes(hipStream_t st, int n, const u64 *side, float *planes);
+void launch_ucb_scores(hipStream_t st, int n, const double *value, const int32_t *visits,
+                       const int32_t *parent_visits, double c_puct, const double *log_table, int log_n,
+                       double *out);
+void launch_tree_init(hipStream_t st, const EngineDev &e);
+void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, int parity);
+hipError_t prepare_tree_fused(size_t lds_bytes);
+void launch_tree_fused(hipStream_t st, const EngineDev &e, const SearchDev &p, size_t lds_bytes);
+void launch_readout(hipStream_t st, const EngineDev &e, const SearchDev &p, int32_t *visits_out,
+                    int8_t *action_out, double *root_value_out, nnb_trajectory *traj, int selfplay);
+void launch_selfplay_init(hipStream_t st, const EngineDev &e, const u64 *start_boards,
+                          const int8_t *start_players, nnb_trajectory *traj, int first_game_id);
+void launch_search_init(hipStream_t st, const EngineDev &e, const u64 *boards, const int8_t *players);
+void launch_stats_reduce(hipStream_t st, const EngineDev &e);
+void launch_fixed_eval(hipStream_t st, const EngineDev &e, const SearchDev &p, const int32_t *count_ptr);
+
+// net_kernels.hip
+struct NetWeights {            // one resident weight set, kernel layouts
+    float *conv0_w, *conv0_b;  // [128][2][4][4], [128]
+    float *conv2_w, *conv2_b;  // repacked [16][16][2][128][4], [128]
+    float *conv4_w, *conv4_b;
+    float *fc_w, *fc_b;        // repacked [1440][2][1024][4], [1024]
+    float *heads_w, *heads_b;  // [8][1024], [8]
+};
+struct NetBuffers {            // activations, channels-last float32
+    float *act1;               // [G][7][8][128]
+    float *act2;               // [G][8][9][128]
+    float *act3;               // [G][9][10][128]
+    float *fc;                 // [G][1024]
+    int max_rows;              // G
+};
+enum NetStage { NET_CONV0 = 0, NET_CONV2 = 1, NET_CONV4 = 2, NET_FC = 3, NET_HEADS = 4 };
+
+hipError_t prepare_net_kernels();
+void launch_repack(hipStream_t st, const NetWeights &dst, const float *conv0_w, const float *conv0_b,
+                   const float *conv2_w, const float *conv2_b, const float *conv4_w, const float *conv4_b,
+                   const float *fc_w, const float *fc_b, const float *policy_w, const float *policy_b,
+                   const float *value_w, const float *value_b);
+void launch_planes_to_bits(hipStream_t st, int n, const float *planes, u64 *side);
+// One stage of the forward pass over `n_max` rows at most; the live row count is read
+// from *count_ptr on the device when count_ptr != nullptr, else it is n_max.
+void launch_net_stage(hipStream_t st, int stage, const NetWeights &w, const NetBuffers &b, const u64 *side,
+                      const uint8_t *legal, float *logp_out, float *value_out, float *prior_out,
+                      const int32_t *count_ptr, int n_max);
+
+}  // namespace nnb

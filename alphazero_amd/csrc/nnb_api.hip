@@ -1,0 +1,478 @@
+// C ABI of libnnb.so (see include/nnb.h): workspace carving, weight loading and the
+// host side of the lock-step search / self-play loops.  No device memory is
+// allocated here: the engine lives in the caller's workspace.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/nnb.h"
+#include "c4_bits.h"
+#include "engine_layout.h"
+#include "kernels.h"
+
+using namespace nnb;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t err__ = (expr);                                                             \
+        if (err__ != hipSuccess)                                                               \
+            return fail(NNB_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(err__), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+constexpr size_t kAlign = 256;
+constexpr int kMaxSims = 9000;           // first_child is 16 bit: 1 + 7*sims <= 65535
+constexpr int kProfClasses = 7;
+constexpr int kProfSamples = 48;         // event pairs per class per drain
+
+struct Carver {
+    unsigned char *base;
+    size_t off = 0;
+    explicit Carver(void *b) : base(static_cast<unsigned char *>(b)) {}
+    template <typename T> T *take(size_t count) {
+        off = (off + kAlign - 1) / kAlign * kAlign;
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+struct ProfClass {
+    hipEvent_t start[kProfSamples], stop[kProfSamples];
+    int used = 0;
+    double total_ms = 0.0;
+    long long launches = 0;
+    long long seen = 0;
+};
+
+}  // namespace
+
+struct nnb_engine {
+    nnb_config cfg;
+    EngineDev dev;
+    NetBuffers buf;
+    std::vector<NetWeights> weights;
+    std::vector<int> weights_loaded;
+    int32_t *host_counters = nullptr;      // pinned, 16 ints
+    unsigned long long *host_stats = nullptr;   // pinned, 8 u64
+    size_t fused_lds_prepared = 0;
+    bool prof_on = false;
+    bool prof_events = false;
+    ProfClass prof[kProfClasses];
+};
+
+namespace {
+
+void carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std::vector<NetWeights> &w) {
+    const size_t G = cfg.max_games;
+    const size_t cap = 1 + 7 * (size_t)cfg.max_sims;
+    d.max_games = cfg.max_games; d.pool_cap = (int32_t)cap; d.max_sims = cfg.max_sims; d.n_games = 0;
+    d.nodes = c.take<Node>(G * cap);
+    d.prior = c.take<float>(G * cap);
+    d.log_table = c.take<double>(cfg.max_sims + 8);
+    d.root_boards = c.take<u64>(2 * G);
+    d.root_player = c.take<int8_t>(G);
+    d.active = c.take<int32_t>(G);
+    d.n_nodes = c.take<int32_t>(G);
+    d.sims_done = c.take<int32_t>(G);
+    d.pending = c.take<int32_t>(G);
+    d.path_len = c.take<int32_t>(G);
+    d.path = c.take<uint16_t>(G * kPathSlots);
+    d.ply = c.take<int32_t>(G);
+    d.game_stats = c.take<int32_t>(4 * G);
+    d.leaf_side = c.take<u64>(2 * G);
+    d.leaf_legal = c.take<uint8_t>(G);
+    d.leaf_count = c.take<int32_t>(64);
+    d.leaf_value = c.take<float>(G);
+    d.leaf_logp = c.take<float>(7 * G);
+    d.leaf_prior = c.take<float>(7 * G);
+    d.counters = c.take<int32_t>(64);
+    d.stats64 = c.take<unsigned long long>(32);
+    b.act1 = c.take<float>(G * 56 * 128);
+    b.act2 = c.take<float>(G * 72 * 128);
+    b.act3 = c.take<float>(G * 90 * 128);
+    b.fc = c.take<float>(G * 1024);
+    b.max_rows = cfg.max_games;
+    w.resize(cfg.n_weight_sets);
+    for (auto &s : w) {
+        s.conv0_w = c.take<float>(128 * 32);  s.conv0_b = c.take<float>(128);
+        s.conv2_w = c.take<float>(128 * 128 * 16);  s.conv2_b = c.take<float>(128);
+        s.conv4_w = c.take<float>(128 * 128 * 16);  s.conv4_b = c.take<float>(128);
+        s.fc_w = c.take<float>((size_t)1024 * 11520);  s.fc_b = c.take<float>(1024);
+        s.heads_w = c.take<float>(8 * 1024);  s.heads_b = c.take<float>(8);
+    }
+    c.take<unsigned char>(kAlign);          // tail pad
+}
+
+int check_cfg(const nnb_config *cfg) {
+    if (!cfg) return fail(NNB_ERR_ARG, "config is null");
+    if (cfg->max_games < 1 || cfg->max_games > (1 << 20))
+        return fail(NNB_ERR_ARG, "max_games %d out of range [1, 2^20]", cfg->max_games);
+    if (cfg->max_sims < 1 || cfg->max_sims > kMaxSims)
+        return fail(NNB_ERR_ARG, "max_sims %d out of range [1, %d]", cfg->max_sims, kMaxSims);
+    if (cfg->n_weight_sets < 1 || cfg->n_weight_sets > 8)
+        return fail(NNB_ERR_ARG, "n_weight_sets %d out of range [1, 8]", cfg->n_weight_sets);
+    return NNB_OK;
+}
+
+// ---- optional per-kernel-class timing with HIP events on the launch stream ----
+struct ProfScope {
+    nnb_engine *e; int cls; hipStream_t st; int slot = -1;
+    ProfScope(nnb_engine *e_, int cls_, hipStream_t st_) : e(e_), cls(cls_), st(st_) {
+        if (!e->prof_on) return;
+        ProfClass &p = e->prof[cls];
+        // sample sparsely: every launch until the pool is half full, then every 37th
+        bool take = p.used < kProfSamples && (p.used < kProfSamples / 2 || p.seen % 37 == 0);
+        ++p.seen;
+        if (take) { slot = p.used++; (void)hipEventRecord(p.start[slot], st); }
+    }
+    ~ProfScope() {
+        if (slot >= 0) (void)hipEventRecord(e->prof[cls].stop[slot], st);
+    }
+};
+
+void prof_drain(nnb_engine *e) {          // call only when the stream is idle
+    if (!e->prof_on) return;
+    for (auto &p : e->prof) {
+        for (int i = 0; i < p.used; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.start[i], p.stop[i]) == hipSuccess) {
+                p.total_ms += ms;
+                ++p.launches;
+            }
+        }
+        p.used = 0;
+    }
+}
+
+SearchDev to_dev(const nnb_search_params &p) {
+    SearchDev s;
+    s.mode = p.mode; s.evaluator = p.evaluator; s.sims = p.sims; s.flags = p.flags;
+    s.c_puct = p.c_puct; s.dirichlet_alpha = p.dirichlet_alpha; s.dirichlet_eps = p.dirichlet_eps;
+    s.seed = p.seed;
+    return s;
+}
+
+int check_params(nnb_engine *e, const nnb_search_params *p, int n) {
+    if (!e) return fail(NNB_ERR_ARG, "engine is null");
+    if (!p) return fail(NNB_ERR_ARG, "params is null");
+    if (n < 1 || n > e->cfg.max_games)
+        return fail(NNB_ERR_ARG, "n = %d out of range [1, max_games = %d]", n, e->cfg.max_games);
+    if (p->sims < 1 || p->sims > e->cfg.max_sims)
+        return fail(NNB_ERR_ARG, "sims = %d out of range [1, max_sims = %d]", p->sims, e->cfg.max_sims);
+    if (p->mode != NNB_MODE_COMPAT)
+        return fail(NNB_ERR_ARG, "mode %d is not supported by this build", p->mode);
+    if (p->evaluator < NNB_EVAL_NET || p->evaluator > NNB_EVAL_HASH_F32)
+        return fail(NNB_ERR_ARG, "evaluator %d is not supported by this build", p->evaluator);
+    if (p->evaluator == NNB_EVAL_NET) {
+        if (p->weight_set < 0 || p->weight_set >= e->cfg.n_weight_sets)
+            return fail(NNB_ERR_ARG, "weight_set %d out of range", p->weight_set);
+        if (!e->weights_loaded[p->weight_set])
+            return fail(NNB_ERR_STATE, "weight set %d has not been loaded (nnb_load_weights)", p->weight_set);
+    }
+    if (!(p->c_puct >= 0.0) || !std::isfinite(p->c_puct)) return fail(NNB_ERR_ARG, "c_puct must be finite and >= 0");
+    return NNB_OK;
+}
+
+// Forward pass over the engine's compacted leaf batch (count on the device).
+void forward_leaves(nnb_engine *e, hipStream_t st, int weight_set, const int32_t *count_ptr, int n_max) {
+    const NetWeights &w = e->weights[weight_set];
+    const EngineDev &d = e->dev;
+    { ProfScope ps(e, 1, st); launch_net_stage(st, NET_CONV0, w, e->buf, d.leaf_side, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
+    { ProfScope ps(e, 2, st); launch_net_stage(st, NET_CONV2, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
+    { ProfScope ps(e, 3, st); launch_net_stage(st, NET_CONV4, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
+    { ProfScope ps(e, 4, st); launch_net_stage(st, NET_FC, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
+    { ProfScope ps(e, 5, st); launch_net_stage(st, NET_HEADS, w, e->buf, nullptr, d.leaf_legal, d.leaf_logp, d.leaf_value, d.leaf_prior, count_ptr, n_max); }
+}
+
+// One move for every live game: S simulations, then the root readout.
+int run_move(nnb_engine *e, hipStream_t st, const nnb_search_params &p, int32_t *visits_out,
+             int8_t *action_out, double *root_value_out, nnb_trajectory *traj, int selfplay,
+             long long *steps) {
+    const SearchDev sd = to_dev(p);
+    const EngineDev &d = e->dev;
+    if (p.evaluator == NNB_EVAL_NET || (p.flags & NNB_FLAG_LOCKSTEP)) {
+        launch_tree_init(st, d);
+        for (int s = 0; s <= p.sims; ++s) {
+            { ProfScope ps(e, 0, st); launch_tree_step(st, d, sd, s & 1); }
+            if (s == p.sims) break;
+            if (p.evaluator == NNB_EVAL_NET) forward_leaves(e, st, p.weight_set, d.leaf_count + (s & 1), d.n_games);
+            else launch_fixed_eval(st, d, sd, d.leaf_count + (s & 1));
+        }
+        *steps += p.sims;
+    } else {
+        size_t lds = (size_t)d.pool_cap * sizeof(Node) + (size_t)(p.sims + 2) * sizeof(double);
+        if (lds > 160 * 1024)
+            return fail(NNB_ERR_ARG, "sims = %d needs %zu bytes of LDS for the fused tree kernel (limit 163840)",
+                        p.sims, lds);
+        if (lds > e->fused_lds_prepared) {
+            HIP_TRY(prepare_tree_fused(lds));
+            e->fused_lds_prepared = lds;
+        }
+        { ProfScope ps(e, 0, st); launch_tree_fused(st, d, sd, lds); }
+        *steps += 1;
+    }
+    { ProfScope ps(e, 6, st); launch_readout(st, d, sd, visits_out, action_out, root_value_out, traj, selfplay); }
+    HIP_TRY(hipGetLastError());
+    return NNB_OK;
+}
+
+int collect_stats(nnb_engine *e, hipStream_t st, nnb_round_stats *out, long long steps, long long rounds, int n) {
+    HIP_TRY(hipMemsetAsync(e->dev.stats64, 0, 8 * sizeof(unsigned long long), st));
+    launch_stats_reduce(st, e->dev);
+    HIP_TRY(hipMemcpyAsync(e->host_stats, e->dev.stats64, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    prof_drain(e);
+    if (out) {
+        out->games = n;
+        out->depth_sum = (int64_t)e->host_stats[0];
+        out->terminal_hits = (int64_t)e->host_stats[1];
+        out->net_leaves = (int64_t)e->host_stats[2];
+        out->sims = (int64_t)e->host_stats[3];
+        out->plies = (int64_t)e->host_stats[4];
+        out->steps = steps;
+        out->moves_rounds = rounds;
+    }
+    return NNB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *nnb_version(void) { return "nnb 0.1 (gfx950)"; }
+const char *nnb_last_error(void) { return g_err; }
+
+int nnb_workspace_bytes(const nnb_config *cfg, size_t *bytes_out) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!bytes_out) return fail(NNB_ERR_ARG, "bytes_out is null");
+    Carver c(nullptr);
+    EngineDev d; NetBuffers b; std::vector<NetWeights> w;
+    carve(*cfg, c, d, b, w);
+    *bytes_out = c.off;
+    return NNB_OK;
+}
+
+int nnb_engine_create(const nnb_config *cfg, void *workspace, size_t workspace_bytes, void *stream,
+                      nnb_engine **engine_out) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!workspace || !engine_out) return fail(NNB_ERR_ARG, "workspace / engine_out is null");
+    if (reinterpret_cast<uintptr_t>(workspace) % kAlign)
+        return fail(NNB_ERR_WORKSPACE, "workspace must be %zu-byte aligned", kAlign);
+    size_t need = 0;
+    nnb_workspace_bytes(cfg, &need);
+    if (workspace_bytes < need)
+        return fail(NNB_ERR_WORKSPACE, "workspace has %zu bytes, %zu needed", workspace_bytes, need);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(cfg->device));
+    nnb_engine *e = new (std::nothrow) nnb_engine();
+    if (!e) return fail(NNB_ERR_ARG, "out of host memory");
+    e->cfg = *cfg;
+    Carver c(workspace);
+    carve(*cfg, c, e->dev, e->buf, e->weights);
+    e->weights_loaded.assign(cfg->n_weight_sets, 0);
+    // zero everything except the (large, fully overwritten) activation and weight areas
+    size_t state_bytes = reinterpret_cast<unsigned char *>(e->buf.act1) - static_cast<unsigned char *>(workspace);
+    HIP_TRY(hipMemsetAsync(workspace, 0, state_bytes, st));
+    // log(n + 1) from the host's libm: the same function CPython's math.log calls (mcts.py:29)
+    std::vector<double> logt(cfg->max_sims + 8);
+    for (size_t n = 0; n < logt.size(); ++n) logt[n] = std::log((double)(n + 1));
+    HIP_TRY(hipMemcpyAsync(e->dev.log_table, logt.data(), logt.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->host_counters), 64 * sizeof(int32_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->host_stats), 32 * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(prepare_net_kernels());
+    HIP_TRY(hipStreamSynchronize(st));
+    *engine_out = e;
+    return NNB_OK;
+}
+
+int nnb_engine_destroy(nnb_engine *e) {
+    if (!e) return NNB_OK;
+    if (e->prof_events)
+        for (auto &p : e->prof)
+            for (int i = 0; i < kProfSamples; ++i) { (void)hipEventDestroy(p.start[i]); (void)hipEventDestroy(p.stop[i]); }
+    if (e->host_counters) (void)hipHostFree(e->host_counters);
+    if (e->host_stats) (void)hipHostFree(e->host_stats);
+    delete e;
+    return NNB_OK;
+}
+
+int nnb_load_weights(nnb_engine *e, int weight_set, void *stream, const float *conv0_w, const float *conv0_b,
+                     const float *conv2_w, const float *conv2_b, const float *conv4_w, const float *conv4_b,
+                     const float *fc_w, const float *fc_b, const float *policy_w, const float *policy_b,
+                     const float *value_w, const float *value_b) {
+    if (!e) return fail(NNB_ERR_ARG, "engine is null");
+    if (weight_set < 0 || weight_set >= e->cfg.n_weight_sets)
+        return fail(NNB_ERR_ARG, "weight_set %d out of range [0, %d)", weight_set, e->cfg.n_weight_sets);
+    if (!conv0_w || !conv0_b || !conv2_w || !conv2_b || !conv4_w || !conv4_b || !fc_w || !fc_b || !policy_w ||
+        !policy_b || !value_w || !value_b)
+        return fail(NNB_ERR_ARG, "a weight pointer is null");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    launch_repack(st, e->weights[weight_set], conv0_w, conv0_b, conv2_w, conv2_b, conv4_w, conv4_b, fc_w, fc_b,
+                  policy_w, policy_b, value_w, value_b);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    e->weights_loaded[weight_set] = 1;
+    return NNB_OK;
+}
+
+int nnb_game_ops(void *stream, int32_t n, const uint64_t *in, const int8_t *players, const int8_t *actions,
+                 uint64_t *out, uint8_t *legal_out, uint8_t *status_out) {
+    if (n < 0) return fail(NNB_ERR_ARG, "n < 0");
+    if (n == 0) return NNB_OK;
+    if (!in) return fail(NNB_ERR_ARG, "colour_boards_in is null");
+    if (actions && !players) return fail(NNB_ERR_ARG, "players is null but actions is given");
+    launch_game_ops(static_cast<hipStream_t>(stream), n, reinterpret_cast<const u64 *>(in), players, actions,
+                    reinterpret_cast<u64 *>(out), legal_out, status_out);
+    HIP_TRY(hipGetLastError());
+    return NNB_OK;
+}
+
+int nnb_encode_planes(void *stream, int32_t n, const uint64_t *side_boards, float *planes_out) {
+    if (n < 0) return fail(NNB_ERR_ARG, "n < 0");
+    if (n == 0) return NNB_OK;
+    if (!side_boards || !planes_out) return fail(NNB_ERR_ARG, "null pointer");
+    launch_encode_planes(static_cast<hipStream_t>(stream), n, reinterpret_cast<const u64 *>(side_boards), planes_out);
+    HIP_TRY(hipGetLastError());
+    return NNB_OK;
+}
+
+int nnb_ucb_scores(nnb_engine *e, void *stream, int32_t n, const double *value_sum, const int32_t *visits,
+                   const int32_t *parent_visits, double c_puct, double *scores_out) {
+    if (!e) return fail(NNB_ERR_ARG, "engine is null");
+    if (n < 0) return fail(NNB_ERR_ARG, "n < 0");
+    if (n == 0) return NNB_OK;
+    if (!value_sum || !visits || !parent_visits || !scores_out) return fail(NNB_ERR_ARG, "null pointer");
+    launch_ucb_scores(static_cast<hipStream_t>(stream), n, value_sum, visits, parent_visits, c_puct,
+                      e->dev.log_table, e->cfg.max_sims + 8, scores_out);
+    HIP_TRY(hipGetLastError());
+    return NNB_OK;
+}
+
+int nnb_net_forward(nnb_engine *e, int weight_set, void *stream, int32_t n, const uint64_t *side_boards,
+                    const uint8_t *legal_masks, float *log_policy_out, float *value_out, float *priors_out) {
+    if (!e) return fail(NNB_ERR_ARG, "engine is null");
+    if (n < 0 || n > e->cfg.max_games) return fail(NNB_ERR_ARG, "n = %d out of range [0, %d]", n, e->cfg.max_games);
+    if (weight_set < 0 || weight_set >= e->cfg.n_weight_sets) return fail(NNB_ERR_ARG, "weight_set out of range");
+    if (!e->weights_loaded[weight_set]) return fail(NNB_ERR_STATE, "weight set %d has not been loaded", weight_set);
+    if (n == 0) return NNB_OK;
+    if (!side_boards) return fail(NNB_ERR_ARG, "side_boards is null");
+    if (priors_out && !legal_masks) return fail(NNB_ERR_ARG, "priors_out needs legal_masks");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const NetWeights &w = e->weights[weight_set];
+    const u64 *side = reinterpret_cast<const u64 *>(side_boards);
+    { ProfScope ps(e, 1, st); launch_net_stage(st, NET_CONV0, w, e->buf, side, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+    { ProfScope ps(e, 2, st); launch_net_stage(st, NET_CONV2, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+    { ProfScope ps(e, 3, st); launch_net_stage(st, NET_CONV4, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+    { ProfScope ps(e, 4, st); launch_net_stage(st, NET_FC, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+    { ProfScope ps(e, 5, st); launch_net_stage(st, NET_HEADS, w, e->buf, nullptr, legal_masks, log_policy_out, value_out, priors_out, nullptr, n); }
+    HIP_TRY(hipGetLastError());
+    return NNB_OK;
+}
+
+int nnb_net_forward_planes(nnb_engine *e, int weight_set, void *stream, int32_t n, const float *planes,
+                           float *log_policy_out, float *value_out) {
+    if (!e) return fail(NNB_ERR_ARG, "engine is null");
+    if (n < 0 || n > e->cfg.max_games) return fail(NNB_ERR_ARG, "n = %d out of range [0, %d]", n, e->cfg.max_games);
+    if (n == 0) return NNB_OK;
+    if (!planes) return fail(NNB_ERR_ARG, "planes is null");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    launch_planes_to_bits(st, n, planes, e->dev.leaf_side);
+    return nnb_net_forward(e, weight_set, stream, n, reinterpret_cast<const uint64_t *>(e->dev.leaf_side), nullptr,
+                           log_policy_out, value_out, nullptr);
+}
+
+int nnb_search(nnb_engine *e, void *stream, const nnb_search_params *params, int32_t n,
+               const uint64_t *root_colour_boards, const int8_t *root_players, int32_t *visits_out,
+               int8_t *action_out, double *root_value_out, nnb_round_stats *stats_out) {
+    int rc = check_params(e, params, n);
+    if (rc) return rc;
+    if (!root_colour_boards || !root_players) return fail(NNB_ERR_ARG, "root boards / players is null");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    e->dev.n_games = n;
+    launch_search_init(st, e->dev, reinterpret_cast<const u64 *>(root_colour_boards), root_players);
+    long long steps = 0;
+    rc = run_move(e, st, *params, visits_out, action_out, root_value_out, nullptr, 0, &steps);
+    if (rc) return rc;
+    return collect_stats(e, st, stats_out, steps, 1, n);
+}
+
+int nnb_selfplay_round(nnb_engine *e, void *stream, const nnb_search_params *params, int32_t n_games,
+                       int32_t first_game_id, const uint64_t *start_colour_boards, const int8_t *start_players,
+                       nnb_trajectory *trajectories_out, nnb_round_stats *stats_out) {
+    int rc = check_params(e, params, n_games);
+    if (rc) return rc;
+    if (!trajectories_out) return fail(NNB_ERR_ARG, "trajectories_out is null");
+    if ((start_colour_boards == nullptr) != (start_players == nullptr))
+        return fail(NNB_ERR_ARG, "start boards and start players must be given together");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    e->dev.n_games = n_games;
+    HIP_TRY(hipMemsetAsync(e->dev.counters, 0, 16 * sizeof(int32_t), st));
+    launch_selfplay_init(st, e->dev, reinterpret_cast<const u64 *>(start_colour_boards), start_players,
+                         trajectories_out, first_game_id);
+    HIP_TRY(hipMemcpyAsync(e->host_counters, e->dev.counters, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    long long steps = 0, rounds = 0;
+    int live = e->host_counters[0];
+    while (live > 0 && rounds < kMaxPlies + 1) {
+        HIP_TRY(hipMemsetAsync(e->dev.counters, 0, 16 * sizeof(int32_t), st));
+        rc = run_move(e, st, *params, nullptr, nullptr, nullptr, trajectories_out, 1, &steps);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(e->host_counters, e->dev.counters, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        prof_drain(e);
+        live = e->host_counters[0];
+        ++rounds;
+    }
+    return collect_stats(e, st, stats_out, steps, rounds, n_games);
+}
+
+int nnb_profile_enable(nnb_engine *e, int on) {
+    if (!e) return fail(NNB_ERR_ARG, "engine is null");
+    if (on && !e->prof_events) {
+        for (auto &p : e->prof)
+            for (int i = 0; i < kProfSamples; ++i) {
+                HIP_TRY(hipEventCreate(&p.start[i]));
+                HIP_TRY(hipEventCreate(&p.stop[i]));
+            }
+        e->prof_events = true;
+    }
+    e->prof_on = on != 0;
+    return NNB_OK;
+}
+
+int nnb_profile_reset(nnb_engine *e) {
+    if (!e) return fail(NNB_ERR_ARG, "engine is null");
+    for (auto &p : e->prof) { p.used = 0; p.total_ms = 0.0; p.launches = 0; p.seen = 0; }
+    return NNB_OK;
+}
+
+int nnb_profile_get(nnb_engine *e, int which, double *avg_ms_out, int64_t *launches_out) {
+    if (!e) return fail(NNB_ERR_ARG, "engine is null");
+    if (which < 0 || which >= kProfClasses) return fail(NNB_ERR_ARG, "class %d out of range", which);
+    const ProfClass &p = e->prof[which];
+    if (avg_ms_out) *avg_ms_out = p.launches ? p.total_ms / (double)p.launches : 0.0;
+    if (launches_out) *launches_out = p.launches;
+    return NNB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,491 @@
+// Game-rule, search-tree and move-readout kernels (gfx950, wave64).
+//
+// One wavefront owns one game's search tree.  Lanes 0..6 score the (at most
+// seven) children of the current node in float64, an 8-lane butterfly picks the
+// best with the lowest column winning ties, and the path from the root is kept
+// one node per lane so the backup is a single atomic-free read-modify-write per
+// lane.  Compile with -ffp-contract=off: the selection score must round exactly
+// like the CPython expression it replaces (nnbattle/agents/alphazero/mcts.py:29).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "c4_bits.h"
+#include "engine_layout.h"
+#include "kernels.h"
+
+namespace nnb {
+
+using c4::u64;
+
+// ---------------------------------------------------------------------------
+// K1: rules on bitboards.  Replaces ConnectFourGame.make_move / get_valid_locations
+// / check_win / is_board_full (connect_four_game.py:38-52,109-125,148-200).
+// ---------------------------------------------------------------------------
+__global__ void game_ops_kernel(int n, const u64 *__restrict__ in, const int8_t *__restrict__ players,
+                                const int8_t *__restrict__ actions, u64 *__restrict__ out,
+                                uint8_t *__restrict__ legal_out, uint8_t *__restrict__ status_out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 b1 = in[2 * i], b2 = in[2 * i + 1];
+    unsigned status = 0;
+    if (actions) {
+        int a = actions[i];
+        if (a >= 0 && a < 7 && ((c4::legal_mask(b1 | b2) >> a) & 1)) {
+            u64 cell = c4::drop_cell(b1 | b2, a);
+            if (players[i] == 1) b1 |= cell; else b2 |= cell;
+            status |= 1;
+        }
+    }
+    if (c4::has_four(b1)) status |= 2;
+    if (c4::has_four(b2)) status |= 4;
+    if (c4::is_full(b1 | b2)) status |= 8;
+    if (out) { out[2 * i] = b1; out[2 * i + 1] = b2; }
+    if (legal_out) legal_out[i] = (uint8_t)c4::legal_mask(b1 | b2);
+    if (status_out) status_out[i] = (uint8_t)status;
+}
+
+// K3: side boards -> float planes [n,2,6,7], row 0 = top (agent_code.py:84-88).
+__global__ void encode_planes_kernel(int n, const u64 *__restrict__ side, float *__restrict__ planes) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;       // one thread per output element
+    if (i >= n * 84) return;
+    int b = i / 84, r = i % 84;
+    int pl = r / 42, cell = r % 42, row = cell / 7, col = cell % 7;
+    u64 bits = side[2 * b + pl];
+    planes[i] = (float)((bits >> (col * 7 + (5 - row))) & 1);
+}
+
+// mcts.py:29 element-wise, float64.
+__global__ void ucb_scores_kernel(int n, const double *__restrict__ value, const int32_t *__restrict__ visits,
+                                  const int32_t *__restrict__ parent_visits, double c_puct,
+                                  const double *__restrict__ log_table, int log_n, double *__restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double d = (double)(visits[i] + 1);
+    int pv = parent_visits[i];
+    double lg = pv < log_n ? log_table[pv] : log((double)(pv + 1));
+    out[i] = (value[i] / d) + c_puct * sqrt(lg / d);
+}
+
+// ---------------------------------------------------------------------------
+// Wave-level search primitives (templated on nothing: Node* may point to global
+// memory or to LDS; after inlining the compiler resolves the address space).
+// ---------------------------------------------------------------------------
+struct Descent {
+    u64 c1, c2;     // colour boards at the leaf
+    int node;       // leaf node index
+    int len;        // nodes on the path, root included
+    bool terminal;  // leaf position is terminal (connect_four_game.py:72-78)
+};
+
+// Selection, agent_code.py:170-176 with MCTSNode.best_child (mcts.py:25-33).
+// `player` is the root mover: the reference flips the mover in make_move
+// (connect_four_game.py:50) and flips it back at agent_code.py:176, so every stone
+// placed during descent has the root mover's colour.  `mypath` is this lane's entry of
+// the path (lane i holds the i-th node).
+__device__ __forceinline__ Descent descend_compat(const Node *pool, const double *logt, double c_puct,
+                                                  int player, u64 c1, u64 c2, int lane, int &mypath) {
+    Descent r;
+    Node root = pool[0];
+    int cur_visits = root.visits, first = root.first_child, nch = root.nchild;
+    r.node = 0; r.len = 1; mypath = 0;
+    r.terminal = c4::is_terminal(c1, c2);
+    while (nch > 0 && !r.terminal) {
+        const bool in = lane < nch;
+        Node ch = pool[first + (in ? lane : 0)];
+        double d = (double)(ch.visits + 1);
+        double score = (ch.value / d) + c_puct * sqrt(logt[cur_visits] / d);
+        if (!in) score = -INFINITY;
+        int best = lane;
+#pragma unroll
+        for (int off = 4; off >= 1; off >>= 1) {
+            double os = __shfl_xor(score, off);
+            int ob = __shfl_xor(best, off);
+            bool take = (os > score) || (os == score && ob < best);   // strict '>' at mcts.py:30
+            score = take ? os : score;
+            best = take ? ob : best;
+        }
+        best = __shfl(best, 0);
+        int a = __shfl((int)ch.action, best);
+        cur_visits = __shfl(ch.visits, best);
+        int nfirst = __shfl((int)ch.first_child, best);
+        int nn = __shfl((int)ch.nchild, best);
+        r.node = first + best;
+        first = nfirst; nch = nn;
+        u64 cell = c4::drop_cell(c1 | c2, a);
+        if (player == 1) c1 |= cell; else c2 |= cell;
+        if (lane == r.len) mypath = r.node;
+        ++r.len;
+        r.terminal = c4::is_terminal(c1, c2);
+    }
+    r.c1 = c1; r.c2 = c2;
+    return r;
+}
+
+// MCTSNode.expand (mcts.py:35-38): one child per legal column, ascending; the
+// reference discards the priors here.  Returns the number of children created.
+__device__ __forceinline__ int expand_compat(Node *pool, int node, int n_nodes, unsigned legal, int lane) {
+    int nlegal = __popc(legal);
+    if (lane < nlegal) {
+        unsigned m = legal;
+        for (int k = 0; k < lane; ++k) m &= m - 1;        // drop the `lane` lowest set bits
+        Node c;
+        c.value = 0.0; c.visits = 0; c.first_child = 0; c.nchild = 0;
+        c.action = (uint8_t)(__ffs(m) - 1);
+        pool[n_nodes + lane] = c;
+    }
+    if (lane == 0) {
+        pool[node].first_child = (uint16_t)n_nodes;
+        pool[node].nchild = (uint8_t)nlegal;
+    }
+    return nlegal;
+}
+
+// MCTSNode.backpropagate (mcts.py:40-44): +1 visit and the same un-negated value on
+// every node of the path; one node per lane, so no atomics.
+__device__ __forceinline__ void backup_path(Node *pool, int mypath, int len, double v, int lane) {
+    if (lane < len) {
+        Node *n = pool + mypath;
+        n->visits += 1;
+        n->value += v;
+    }
+}
+
+__device__ __forceinline__ void wave_mem_sync() {
+    // lanes of this wave read nodes other lanes of the same wave just wrote
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ double fixed_eval(int evaluator, u64 me, u64 opp) {
+    if (evaluator == NNB_EVAL_HASH_Q8) return c4::hash_value_q8(me, opp);
+    if (evaluator == NNB_EVAL_HASH_F32) return c4::hash_value_f32(me, opp);
+    return 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// Start of a move: every live game gets a fresh tree whose root has visits = 1
+// (agent_code.py:159-160).
+// ---------------------------------------------------------------------------
+__global__ void tree_init_kernel(EngineDev e) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) { e.leaf_count[0] = 0; e.leaf_count[1] = 0; }
+    if (g >= e.n_games) return;
+    if (!e.active[g]) return;
+    Node r;
+    r.value = 0.0; r.visits = 1; r.first_child = 0; r.nchild = 0; r.action = 0xFF;
+    e.nodes[(size_t)g * e.pool_cap] = r;
+    e.n_nodes[g] = 1;
+    e.sims_done[g] = 0;
+    e.pending[g] = -1;
+    e.path_len[g] = 0;
+}
+
+// ---------------------------------------------------------------------------
+// K2, lock-step form (NET evaluator): one launch per simulation round.
+//   1. back up the value the network produced for this game's pending leaf;
+//   2. run simulations until one needs the network (a non-terminal leaf) or the
+//      budget is used up; terminal leaves are backed up on the spot
+//      (agent_code.py:182-186);
+//   3. expand the leaf, append its side boards to the compacted leaf batch and
+//      remember the path for step 1 of the next launch.
+// Launch with 256 threads = 4 games per block.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tree_step_kernel(EngineDev e, SearchDev p, int parity) {
+    const int lane = threadIdx.x & 63;
+    const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0) e.leaf_count[parity ^ 1] = 0;
+    if (g >= e.n_games) return;
+    if (!e.active[g]) return;
+
+    Node *pool = e.nodes + (size_t)g * e.pool_cap;
+    int sims_done = e.sims_done[g];
+    int n_nodes = e.n_nodes[g];
+    const int player = e.root_player[g];
+    const u64 r1 = e.root_boards[2 * g], r2 = e.root_boards[2 * g + 1];
+    int depth_sum = 0, term_hits = 0, leaves = 0;
+
+    int pend = e.pending[g];
+    if (pend >= 0) {
+        int len = e.path_len[g];
+        int mypath = e.path[g * kPathSlots + lane];
+        double v = (double)e.leaf_value[pend];           // value.item(), agent_code.py:213
+        backup_path(pool, mypath, len, v, lane);
+        wave_mem_sync();
+        ++sims_done;
+        pend = -1;
+    }
+
+    while (sims_done < p.sims) {
+        int mypath;
+        Descent d = descend_compat(pool, e.log_table, p.c_puct, player, r1, r2, lane, mypath);
+        depth_sum += d.len - 1;
+        unsigned legal = c4::legal_mask(d.c1 | d.c2);
+        if (d.terminal || legal == 0) {
+            // agent_code.py:182-186 and :190-193
+            double v = d.terminal ? c4::reward(d.c1, d.c2) : 0.0;
+            backup_path(pool, mypath, d.len, v, lane);
+            wave_mem_sync();
+            ++sims_done; ++term_hits;
+            continue;
+        }
+        n_nodes += expand_compat(pool, d.node, n_nodes, legal, lane);
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&e.leaf_count[parity], 1);
+        slot = __shfl(slot, 0);
+        if (lane == 0) {
+            // the leaf is encoded from the root mover's side at every depth (agent_code.py:85)
+            e.leaf_side[2 * slot] = player == 1 ? d.c1 : d.c2;
+            e.leaf_side[2 * slot + 1] = player == 1 ? d.c2 : d.c1;
+            e.leaf_legal[slot] = (uint8_t)legal;
+            e.path_len[g] = d.len;
+        }
+        e.path[g * kPathSlots + lane] = (uint16_t)mypath;
+        pend = slot;
+        ++leaves;
+        break;
+    }
+
+    if (lane == 0) {
+        e.sims_done[g] = sims_done;
+        e.n_nodes[g] = n_nodes;
+        e.pending[g] = pend;
+        int32_t *st = e.game_stats + 4 * g;
+        st[0] += depth_sum; st[1] += term_hits; st[2] += leaves;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2, fused form (CONST / HASH evaluators): the whole search of one move in one
+// launch, node pool and log table resident in LDS.  One 64-thread block per game.
+// Dynamic LDS: pool_cap*16 bytes of nodes followed by (sims+2) doubles.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void tree_fused_kernel(EngineDev e, SearchDev p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x;
+    if (g >= e.n_games) return;
+    if (!e.active[g]) return;
+    Node *pool = reinterpret_cast<Node *>(smem);
+    double *logt = reinterpret_cast<double *>(smem + (size_t)e.pool_cap * sizeof(Node));
+    for (int i = lane; i < p.sims + 2; i += 64) logt[i] = e.log_table[i];
+    if (lane == 0) {
+        Node r;
+        r.value = 0.0; r.visits = 1; r.first_child = 0; r.nchild = 0; r.action = 0xFF;
+        pool[0] = r;
+    }
+    __syncthreads();
+
+    const int player = e.root_player[g];
+    const u64 r1 = e.root_boards[2 * g], r2 = e.root_boards[2 * g + 1];
+    int n_nodes = 1, depth_sum = 0, term_hits = 0, leaves = 0;
+    for (int s = 0; s < p.sims; ++s) {
+        int mypath;
+        Descent d = descend_compat(pool, logt, p.c_puct, player, r1, r2, lane, mypath);
+        depth_sum += d.len - 1;
+        unsigned legal = c4::legal_mask(d.c1 | d.c2);
+        double v;
+        if (d.terminal || legal == 0) {
+            v = d.terminal ? c4::reward(d.c1, d.c2) : 0.0;
+            ++term_hits;
+        } else {
+            n_nodes += expand_compat(pool, d.node, n_nodes, legal, lane);
+            v = fixed_eval(p.evaluator, player == 1 ? d.c1 : d.c2, player == 1 ? d.c2 : d.c1);
+            ++leaves;
+        }
+        backup_path(pool, mypath, d.len, v, lane);
+        __syncthreads();
+    }
+    // hand the root and its children to the readout kernel through the global pool
+    Node *gpool = e.nodes + (size_t)g * e.pool_cap;
+    if (lane < 8 && lane < n_nodes) gpool[lane] = pool[lane];
+    if (lane == 0) {
+        e.sims_done[g] = p.sims;
+        e.n_nodes[g] = n_nodes;
+        e.pending[g] = -1;
+        int32_t *st = e.game_stats + 4 * g;
+        st[0] += depth_sum; st[1] += term_hits; st[2] += leaves;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K7: end of a move.  Root readout (agent_code.py:217-229: most visited child, first
+// maximum = lowest column), then for self-play the move is applied, the ply is
+// appended to the game's trajectory and finished games are retired
+// (train_alpha_zero.py:41-48).  One thread per game.
+// ---------------------------------------------------------------------------
+__global__ void readout_kernel(EngineDev e, SearchDev p, int32_t *__restrict__ visits_out,
+                               int8_t *__restrict__ action_out, double *__restrict__ root_value_out,
+                               nnb_trajectory *__restrict__ traj, int selfplay) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= e.n_games) return;
+    if (!e.active[g]) return;
+    const Node *pool = e.nodes + (size_t)g * e.pool_cap;
+    Node root = pool[0];
+    int vis[7] = {0, 0, 0, 0, 0, 0, 0};
+    int best_a = -1, best_v = -1;
+    for (int k = 0; k < root.nchild; ++k) {
+        Node ch = pool[root.first_child + k];
+        vis[ch.action] = ch.visits;
+        if (ch.visits > best_v) { best_v = ch.visits; best_a = ch.action; }
+    }
+    if (visits_out)
+        for (int c = 0; c < 7; ++c) visits_out[7 * g + c] = vis[c];
+    if (action_out) action_out[g] = (int8_t)best_a;
+    if (root_value_out) root_value_out[g] = root.value;
+    e.game_stats[4 * g + 3] += e.sims_done[g];
+    if (!selfplay) return;
+
+    u64 b1 = e.root_boards[2 * g], b2 = e.root_boards[2 * g + 1];
+    int player = e.root_player[g];
+    int ply = e.ply[g];
+    nnb_trajectory *t = traj + g;
+    bool done = best_a < 0 || ply >= kMaxPlies;
+    if (!done) {
+        nnb_ply *rec = &t->plies[ply];
+        rec->colour_boards[0] = b1; rec->colour_boards[1] = b2;
+        for (int c = 0; c < 7; ++c) rec->visits[c] = (uint16_t)vis[c];
+        rec->action = (uint8_t)best_a;
+        rec->player = (uint8_t)player;
+        u64 cell = c4::drop_cell(b1 | b2, best_a);            // game.make_move, train_alpha_zero.py:44
+        if (player == 1) b1 |= cell; else b2 |= cell;
+        player = 3 - player;                                  // connect_four_game.py:50
+        ++ply;
+        e.root_boards[2 * g] = b1; e.root_boards[2 * g + 1] = b2;
+        e.root_player[g] = (int8_t)player;
+        e.ply[g] = ply;
+        done = c4::is_terminal(b1, b2);                       // train_alpha_zero.py:41
+    }
+    if (done) {
+        e.active[g] = 0;
+        t->length = ply;
+        t->result = c4::result(b1, b2);                       // train_alpha_zero.py:48
+        t->final_boards[0] = b1; t->final_boards[1] = b2;
+    } else {
+        atomicAdd(&e.counters[0], 1);
+    }
+}
+
+// Self-play set-up: empty boards (ConnectFourGame.reset, connect_four_game.py:30-36)
+// or caller-supplied start positions; games that start terminal are retired at once.
+__global__ void selfplay_init_kernel(EngineDev e, const u64 *__restrict__ start_boards,
+                                     const int8_t *__restrict__ start_players,
+                                     nnb_trajectory *__restrict__ traj, int first_game_id) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= e.n_games) return;
+    u64 b1 = start_boards ? start_boards[2 * g] : 0, b2 = start_boards ? start_boards[2 * g + 1] : 0;
+    int player = start_players ? start_players[g] : 1;
+    e.root_boards[2 * g] = b1; e.root_boards[2 * g + 1] = b2;
+    e.root_player[g] = (int8_t)player;
+    e.ply[g] = 0;
+    for (int k = 0; k < 4; ++k) e.game_stats[4 * g + k] = 0;
+    nnb_trajectory *t = traj + g;
+    t->length = 0; t->result = 2; t->game_id = first_game_id + g; t->reserved = 0;
+    t->final_boards[0] = b1; t->final_boards[1] = b2;
+    bool term = c4::is_terminal(b1, b2);
+    e.active[g] = term ? 0 : 1;
+    if (term) t->result = c4::result(b1, b2);
+    else atomicAdd(&e.counters[0], 1);
+}
+
+// Search-only set-up: caller-supplied roots, every root searched.
+__global__ void search_init_kernel(EngineDev e, const u64 *__restrict__ boards,
+                                   const int8_t *__restrict__ players) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= e.n_games) return;
+    e.root_boards[2 * g] = boards[2 * g]; e.root_boards[2 * g + 1] = boards[2 * g + 1];
+    e.root_player[g] = players[g];
+    e.active[g] = 1;
+    e.ply[g] = 0;
+    for (int k = 0; k < 4; ++k) e.game_stats[4 * g + k] = 0;
+}
+
+// Sums the per-game statistics into counters[8..11] (depth, terminal hits, leaves, sims)
+// and counters[12] (plies).
+__global__ void stats_reduce_kernel(EngineDev e) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    long long v[5] = {0, 0, 0, 0, 0};
+    if (g < e.n_games) {
+        for (int k = 0; k < 4; ++k) v[k] = e.game_stats[4 * g + k];
+        v[4] = e.ply[g];
+    }
+    for (int k = 0; k < 5; ++k) {
+        long long x = v[k];
+        for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+        if ((threadIdx.x & 63) == 0 && x)
+            atomicAdd(reinterpret_cast<unsigned long long *>(e.stats64) + k, (unsigned long long)x);
+    }
+}
+
+// Fixed evaluators over the compacted leaf batch: fills the value buffer exactly as the
+// network's heads kernel would, so the lock-step path can be run without weights.
+__global__ void fixed_eval_kernel(EngineDev e, SearchDev p, const int32_t *__restrict__ count_ptr) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *count_ptr) return;
+    e.leaf_value[i] = (float)fixed_eval(p.evaluator, e.leaf_side[2 * i], e.leaf_side[2 * i + 1]);
+}
+
+// ---------------------------------------------------------------------------
+// Host launchers
+// ---------------------------------------------------------------------------
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+void launch_game_ops(hipStream_t st, int n, const u64 *in, const int8_t *players, const int8_t *actions,
+                     u64 *out, uint8_t *legal_out, uint8_t *status_out) {
+    if (n <= 0) return;
+    game_ops_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, in, players, actions, out, legal_out, status_out);
+}
+
+void launch_encode_planes(hipStream_t st, int n, const u64 *side, float *planes) {
+    if (n <= 0) return;
+    encode_planes_kernel<<<cdiv(n * 84, 256), 256, 0, st>>>(n, side, planes);
+}
+
+void launch_ucb_scores(hipStream_t st, int n, const double *value, const int32_t *visits,
+                       const int32_t *parent_visits, double c_puct, const double *log_table, int log_n,
+                       double *out) {
+    if (n <= 0) return;
+    ucb_scores_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, value, visits, parent_visits, c_puct, log_table,
+                                                    log_n, out);
+}
+
+void launch_tree_init(hipStream_t st, const EngineDev &e) {
+    tree_init_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e);
+}
+
+void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, int parity) {
+    tree_step_kernel<<<cdiv(e.n_games, 4), 256, 0, st>>>(e, p, parity);
+}
+
+hipError_t prepare_tree_fused(size_t lds_bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(tree_fused_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}
+
+void launch_tree_fused(hipStream_t st, const EngineDev &e, const SearchDev &p, size_t lds_bytes) {
+    tree_fused_kernel<<<e.n_games, 64, lds_bytes, st>>>(e, p);
+}
+
+void launch_readout(hipStream_t st, const EngineDev &e, const SearchDev &p, int32_t *visits_out,
+                    int8_t *action_out, double *root_value_out, nnb_trajectory *traj, int selfplay) {
+    readout_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, p, visits_out, action_out, root_value_out, traj,
+                                                         selfplay);
+}
+
+void launch_selfplay_init(hipStream_t st, const EngineDev &e, const u64 *start_boards,
+                          const int8_t *start_players, nnb_trajectory *traj, int first_game_id) {
+    selfplay_init_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, start_boards, start_players, traj,
+                                                               first_game_id);
+}
+
+void launch_search_init(hipStream_t st, const EngineDev &e, const u64 *boards, const int8_t *players) {
+    search_init_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, boards, players);
+}
+
+void launch_fixed_eval(hipStream_t st, const EngineDev &e, const SearchDev &p, const int32_t *count_ptr) {
+    fixed_eval_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, p, count_ptr);
+}
+
+void launch_stats_reduce(hipStream_t st, const EngineDev &e) {
+    stats_reduce_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e);
+}
+
+}  // namespace nnb

@@ -1,0 +1,226 @@
+/*
+ * nnb.h - C ABI of libnnb.so, the MI355X (gfx950) self-play engine behind the
+ * nnbattle agent/game API.
+ *
+ * The reference (jahoops/alphazero, package `nnbattle`) has no FFI: its hot
+ * path is Python.  Each entry point below names the reference code it replaces
+ * (paths under the reference root).  The Python classes in alphazero_amd/ keep
+ * the reference's names and signatures and call these functions through ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative nnb_status on error;
+ *     nnb_last_error() returns the message of the calling thread's last error;
+ *   - all array arguments are DEVICE pointers owned by the caller (for example
+ *     torch tensors' data_ptr()); the library never frees them;
+ *   - work is enqueued on the caller's HIP stream (`stream`, a hipStream_t passed
+ *     as void*; NULL = the default stream); functions documented as
+ *     "synchronous" wait for the stream before returning;
+ *   - one host thread per engine; calls on one engine must not overlap;
+ *   - the engine owns no device memory of its own: it lives in a workspace the
+ *     caller allocates (nnb_workspace_bytes) and hands to nnb_engine_create.
+ *
+ * Bitboards: a position is two uint64 words.  Bit index = col*7 + row_from_bottom
+ * (row_from_bottom = 5 - the reference's row index; its row 0 is the top row,
+ * nnbattle/game/connect_four_game.py:21,47).  Bit 6 of each 7-bit column is zero.
+ * "Colour boards" are (colour-1 stones, colour-2 stones); "side boards" are
+ * (stones of the side the network looks from, opponent stones), the bit form of
+ * AlphaZeroAgent.preprocess (nnbattle/agents/alphazero/agent_code.py:76-89).
+ */
+#ifndef NNB_H
+#define NNB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nnb_engine nnb_engine;
+
+enum nnb_status {
+    NNB_OK = 0,
+    NNB_ERR_ARG = -1,       /* bad argument (null pointer, size out of range ...) */
+    NNB_ERR_HIP = -2,       /* a HIP runtime call failed                          */
+    NNB_ERR_STATE = -3,     /* call order violated (e.g. weights not loaded)      */
+    NNB_ERR_WORKSPACE = -4  /* workspace too small or misaligned                  */
+};
+
+/* Search rule.  COMPAT reproduces the reference search bit for bit
+ * (agent_code.py:144-234, mcts.py:25-44), including its quirks.  AZ is the PUCT
+ * rule with priors, Dirichlet root noise, side-alternating descent and a
+ * sign-flipped backup; it has no counterpart in the reference. */
+enum nnb_mode { NNB_MODE_COMPAT = 0, NNB_MODE_AZ = 1 };
+
+/* Leaf evaluator.  NET is the policy-value network (network.py:43-50).  The other
+ * three are fixed functions of the leaf position used for bit-exact parity runs
+ * and tree-only benchmarks: CONST = value 0 / uniform priors; HASH_Q8 and
+ * HASH_F32 = a 64-bit mix of the side boards mapped to a multiple of 1/256 or to
+ * a float32; ROLLOUT = uniform priors and a uniformly random playout. */
+enum nnb_evaluator {
+    NNB_EVAL_NET = 0,
+    NNB_EVAL_CONST = 1,
+    NNB_EVAL_HASH_Q8 = 2,
+    NNB_EVAL_HASH_F32 = 3,
+    NNB_EVAL_ROLLOUT = 4
+};
+
+/* nnb_search_params.flags */
+enum nnb_flags {
+    /* Run a fixed evaluator through the lock-step path (tree step kernel, leaf batch,
+     * value buffer) that NET uses, instead of the fused one-launch kernel.  Same
+     * results; exists so the lock-step machinery can be checked bit for bit. */
+    NNB_FLAG_LOCKSTEP = 1
+};
+
+typedef struct nnb_config {
+    int32_t max_games;   /* concurrent games / root positions per call (>= 1)      */
+    int32_t max_sims;    /* simulations per move; node pool = 1 + 7*max_sims nodes */
+    int32_t device;      /* HIP device ordinal the workspace lives on              */
+    int32_t n_weight_sets; /* resident network weight sets (1, or 2 for an arena)  */
+} nnb_config;
+
+typedef struct nnb_search_params {
+    int32_t mode;        /* nnb_mode                                               */
+    int32_t evaluator;   /* nnb_evaluator                                          */
+    int32_t sims;        /* simulations per move (agent.num_simulations)           */
+    int32_t weight_set;  /* which resident weight set NET uses                     */
+    int32_t flags;       /* NNB_FLAG_* bits                                        */
+    int32_t reserved;
+    double  c_puct;      /* exploration constant (agent.c_puct, default 1.4)       */
+    double  dirichlet_alpha;   /* AZ only; 0 disables root noise                   */
+    double  dirichlet_eps;     /* AZ only; mixing weight of the noise              */
+    uint64_t seed;       /* AZ noise / ROLLOUT playouts: counter-based RNG key     */
+} nnb_search_params;
+
+/* One finished (or cut-off) self-play game.  Fixed size so records can be
+ * all-gathered across ranks as raw bytes.  What train_alpha_zero.py:33-55 and
+ * agent_code.py:254-267 keep per game is derivable from it. */
+typedef struct nnb_ply {
+    uint64_t colour_boards[2];   /* position BEFORE the move                        */
+    uint16_t visits[7];          /* root child visit counts (agent_code.py:218-229) */
+    uint8_t  action;             /* column played                                   */
+    uint8_t  player;             /* colour that moved (1 or 2)                      */
+} nnb_ply;                       /* 32 bytes */
+
+typedef struct nnb_trajectory {
+    int32_t  length;             /* plies played                                    */
+    int32_t  result;             /* get_result(): +1 colour 1 won, -1 colour 2, 0 draw; 2 = unfinished */
+    int32_t  game_id;            /* global game index                               */
+    int32_t  reserved;
+    uint64_t final_boards[2];    /* colour boards after the last move               */
+    nnb_ply  plies[42];
+} nnb_trajectory;                /* 32 + 42*32 = 1376 bytes */
+
+typedef struct nnb_round_stats {
+    int64_t games;               /* games played                                    */
+    int64_t plies;               /* total moves over all games                      */
+    int64_t sims;                /* total simulations                               */
+    int64_t net_leaves;          /* leaves sent through the network                 */
+    int64_t terminal_hits;       /* simulations that ended on a terminal node       */
+    int64_t depth_sum;           /* sum of selection depths over all simulations    */
+    int64_t steps;               /* lock-step iterations (tree kernel + forward)    */
+    int64_t moves_rounds;        /* move rounds (<= 42)                             */
+} nnb_round_stats;
+
+/* ---- library ----------------------------------------------------------- */
+const char *nnb_version(void);
+const char *nnb_last_error(void);
+
+/* ---- engine life cycle -------------------------------------------------- */
+/* Bytes of device workspace an engine of this configuration needs. */
+int nnb_workspace_bytes(const nnb_config *cfg, size_t *bytes_out);
+
+/* Builds an engine inside `workspace` (device memory, 256-byte aligned, at least
+ * nnb_workspace_bytes() long, zero-filled by this call).  Synchronous.
+ * Replaces: AlphaZeroAgent.__init__ (agent_code.py:27-59) as far as device state goes. */
+int nnb_engine_create(const nnb_config *cfg, void *workspace, size_t workspace_bytes,
+                      void *stream, nnb_engine **engine_out);
+int nnb_engine_destroy(nnb_engine *engine);
+
+/* Repacks the ten float32 state-dict tensors of Connect4Net (network.py:28-41, keys
+ * conv_layers.{0,2,4}.{weight,bias}, fc_layers.0.{weight,bias},
+ * policy_head.{weight,bias}, value_head.{weight,bias}; device pointers, PyTorch
+ * layouts) into the engine's kernel layouts.  Replaces: load_agent_model's
+ * load_state_dict (utils.py:40-46). */
+int nnb_load_weights(nnb_engine *engine, int weight_set, void *stream,
+                     const float *conv0_w, const float *conv0_b,
+                     const float *conv2_w, const float *conv2_b,
+                     const float *conv4_w, const float *conv4_b,
+                     const float *fc_w, const float *fc_b,
+                     const float *policy_w, const float *policy_b,
+                     const float *value_w, const float *value_b);
+
+/* ---- K1: game rules on bitboards ---------------------------------------- */
+/* For each of n positions: if actions[i] >= 0, drop a stone of colour players[i]
+ * in that column (ConnectFourGame.make_move, connect_four_game.py:38-52: a full
+ * column changes nothing).  Then report, for the resulting position,
+ *   legal_out[i]  : 7-bit mask of open columns (get_valid_locations, :109-125)
+ *   status_out[i] : bit0 = move applied, bit1 = colour 1 has four, bit2 = colour 2
+ *                   has four (check_win, :148-192), bit3 = board full (:194-200);
+ *                   is_terminal (:72-78) = any of bits 1-3.
+ * actions may be NULL (no move; bit0 is then 0). */
+int nnb_game_ops(void *stream, int32_t n, const uint64_t *colour_boards_in, const int8_t *players,
+                 const int8_t *actions, uint64_t *colour_boards_out, uint8_t *legal_out,
+                 uint8_t *status_out);
+
+/* K3: side boards -> float32 planes [n,2,6,7] (AlphaZeroAgent.preprocess,
+ * agent_code.py:76-89; row 0 of a plane is the top row). */
+int nnb_encode_planes(void *stream, int32_t n, const uint64_t *side_boards, float *planes_out);
+
+/* Selection score of mcts.py:29 in float64, element-wise:
+ * value/(visits+1) + c_puct*sqrt(log(parent_visits+1)/(visits+1)), with log taken
+ * from the engine's table (filled by the host's libm) for parent_visits <= max_sims. */
+int nnb_ucb_scores(nnb_engine *engine, void *stream, int32_t n, const double *value_sum,
+                   const int32_t *visits, const int32_t *parent_visits, double c_puct,
+                   double *scores_out);
+
+/* ---- K4-K6: policy-value network ---------------------------------------- */
+/* Connect4Net.forward (network.py:43-50) for n <= max_games positions given as
+ * side boards.  log_policy_out [n,7] and value_out [n] as the reference returns
+ * them.  If legal_masks != NULL, priors_out [n,7] receives exp(log_policy) with
+ * illegal columns zeroed and renormalised, uniform over legal columns if the sum
+ * is 0 (agent_code.py:199-208).  Any output pointer may be NULL. */
+int nnb_net_forward(nnb_engine *engine, int weight_set, void *stream, int32_t n,
+                    const uint64_t *side_boards, const uint8_t *legal_masks,
+                    float *log_policy_out, float *value_out, float *priors_out);
+
+/* Same from float32 planes [n,2,6,7] whose entries are exactly 0 or 1. */
+int nnb_net_forward_planes(nnb_engine *engine, int weight_set, void *stream, int32_t n,
+                           const float *planes, float *log_policy_out, float *value_out);
+
+/* ---- K2 + K7: search ----------------------------------------------------- */
+/* Runs one search per root position (AlphaZeroAgent.mcts_simulate,
+ * agent_code.py:144-234) for n <= max_games independent roots, one wavefront per
+ * root.  visits_out [n,7] = root child visit counts (0 where no child),
+ * action_out [n] = most visited child, lowest column on ties, -1 if the root got no
+ * children (the reference returns None, agent_code.py:219-221).
+ * root_value_out [n] (may be NULL) = the root's accumulated value sum.
+ * stats_out (host pointer, may be NULL) is filled when the call returns.  Synchronous. */
+int nnb_search(nnb_engine *engine, void *stream, const nnb_search_params *params, int32_t n,
+               const uint64_t *root_colour_boards, const int8_t *root_players,
+               int32_t *visits_out, int8_t *action_out, double *root_value_out,
+               nnb_round_stats *stats_out);
+
+/* Plays n_games <= max_games self-play games to the end in lock step, the same
+ * searcher on both sides (self_play, train_alpha_zero.py:33-55).  Game i starts from
+ * the empty board, or from start_colour_boards[i]/start_players[i] when given, and
+ * is recorded in trajectories_out[i] (device memory, n_games records) with
+ * game_id = first_game_id + i.  stats_out is a host pointer.  Synchronous. */
+int nnb_selfplay_round(nnb_engine *engine, void *stream, const nnb_search_params *params,
+                       int32_t n_games, int32_t first_game_id,
+                       const uint64_t *start_colour_boards, const int8_t *start_players,
+                       nnb_trajectory *trajectories_out, nnb_round_stats *stats_out);
+
+/* Average device time, in milliseconds, of the `which`-th engine kernel class since
+ * the last nnb_profile_reset, measured with HIP events on the launch stream when
+ * profiling is enabled (nnb_profile_enable(engine, 1)).  Classes: 0 tree step,
+ * 1 conv0, 2 conv2, 3 conv4, 4 fc, 5 heads, 6 move readout. */
+int nnb_profile_enable(nnb_engine *engine, int on);
+int nnb_profile_reset(nnb_engine *engine);
+int nnb_profile_get(nnb_engine *engine, int which, double *avg_ms_out, int64_t *launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNB_H */
