@@ -75,6 +75,7 @@ struct nnb_engine {
     size_t fused_lds_prepared = 0;
     bool prof_on = false;
     bool prof_events = false;
+    int prof_stride = 1;
     ProfClass prof[kProfClasses];
 };
 
@@ -138,8 +139,8 @@ struct ProfScope {
     ProfScope(nnb_engine *e_, int cls_, hipStream_t st_) : e(e_), cls(cls_), st(st_) {
         if (!e->prof_on) return;
         ProfClass &p = e->prof[cls];
-        // sample sparsely: every launch until the pool is half full, then every 37th
-        bool take = p.used < kProfSamples && (p.used < kProfSamples / 2 || p.seen % 37 == 0);
+        // uniform sample over the launches of one move, so the mean is unbiased
+        bool take = p.used < kProfSamples && p.seen % e->prof_stride == 0;
         ++p.seen;
         if (take) { slot = p.used++; (void)hipEventRecord(p.start[slot], st); }
     }
@@ -159,6 +160,7 @@ void prof_drain(nnb_engine *e) {          // call only when the stream is idle
             }
         }
         p.used = 0;
+        p.seen = 0;
     }
 }
 
@@ -208,6 +210,7 @@ int run_move(nnb_engine *e, hipStream_t st, const nnb_search_params &p, int32_t 
              long long *steps) {
     const SearchDev sd = to_dev(p);
     const EngineDev &d = e->dev;
+    e->prof_stride = p.sims / kProfSamples + 1;
     if (p.evaluator == NNB_EVAL_NET || (p.flags & NNB_FLAG_LOCKSTEP)) {
         launch_tree_init(st, d);
         for (int s = 0; s <= p.sims; ++s) {

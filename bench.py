@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Self-play throughput benchmark (BASELINE.json config 2 at N=1, config 3 at N>1).
+
+One "step" = one self-play round: every rank plays GAMES_PER_GPU concurrent Connect Four
+games to the end with the reference's search (200 simulations per move, same searcher
+on both sides, random-init seed-0 Connect4Net as the leaf evaluator, all leaves of a
+simulation round batched into one forward pass), then the finished trajectories are
+all-gathered over RCCL.  Weak scaling: per-GPU work is fixed.
+
+    python bench.py --gpus 1 --steps 1 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     : the dominant kernel's algorithmic FLOP rate against the MI355X f32 matrix peak,
+                 its duration measured with HIP events on the launch stream inside this run;
+  cpu_baseline : the CPU restatement of the reference path (oracle/ref_port.py: numpy board,
+                 one game at a time, batch-1 torch-CPU forward) timed on this box's host cores
+                 on a bounded sample (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GAMES_PER_GPU = 4096
+SIMS = 200
+C_PUCT = 1.4
+
+# algorithmic FLOP per evaluated leaf (2 x MAC), network.py:28-41
+FLOP_PER_LEAF = {
+    "conv0": 2 * 128 * 7 * 8 * (2 * 16),
+    "conv2": 2 * 128 * 8 * 9 * (128 * 16),
+    "conv4": 2 * 128 * 9 * 10 * (128 * 16),
+    "fc": 2 * 11520 * 1024,
+    "heads": 2 * 1024 * 8,
+}
+PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X dense f32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(sims: int, plies_per_game: float, budget_s: float = 25.0) -> dict:
+    """Times the CPU restatement of the reference self-play path on a bounded sample."""
+    import torch
+    from oracle import ref_port as rp
+    sd = rp.seeded_state_dict(0)
+    ev = rp.make_net_evaluator(sd)
+    board, player = rp.new_board(), 1
+    t0 = time.perf_counter()
+    plies = 0
+    done = False
+    while not rp.is_terminal(board):
+        a, _ = rp.compat_search(board, player, sims, C_PUCT, ev)
+        _, player = rp.make_move(board, player, a)
+        plies += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    else:
+        done = True
+    dt = time.perf_counter() - t0
+    sims_per_s = plies * sims / dt
+    if done:
+        games_per_s = 1.0 / dt
+        sample = f"1 complete game, {plies} plies x {sims} sims, {dt:.1f} s"
+    else:
+        games_per_s = sims_per_s / (sims * max(plies_per_game, 1.0))
+        sample = (f"first {plies} plies x {sims} sims of one game in {dt:.1f} s; games/s extrapolated to "
+                  f"{plies_per_game:.1f} plies per game")
+    return {"value": games_per_s, "unit": "games/s", "sims_per_s": sims_per_s,
+            "cores": torch.get_num_threads(), "kind": "port", "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--games", type=int, default=GAMES_PER_GPU, help="concurrent games per GPU")
+    ap.add_argument("--sims", type=int, default=SIMS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from alphazero_amd.engine import TRAJECTORY_BYTES, Engine
+    from alphazero_amd.network import seeded_state_dict
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU "
+                         "(python -m torch.distributed.run --nproc-per-node N ...)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    G = args.games
+    engine = Engine(max_games=G, max_sims=args.sims, device=device)
+    engine.load_state_dict(seeded_state_dict(0))
+    params = engine.params(args.sims, C_PUCT, evaluator="net", mode="compat")
+    traj = torch.empty((G, TRAJECTORY_BYTES), dtype=torch.uint8, device=device)
+    replay = torch.empty((world * G, TRAJECTORY_BYTES), dtype=torch.uint8, device=device) if world > 1 else traj
+
+    def one_round(step_idx: int):
+        _, stats = engine.selfplay_round(G, params, first_game_id=(step_idx * world + rank) * G, out=traj)
+        if world > 1:
+            dist.all_gather_into_tensor(replay, traj)      # RCCL: trajectories into every rank's buffer
+        return stats
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for w in range(args.warmup):
+        one_round(w)
+    engine.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    totals = {}
+    for k in range(args.steps):
+        st = one_round(args.warmup + k)
+        for key, v in st.items():
+            totals[key] = totals.get(key, 0) + v
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = engine.profile_report()
+    engine.profile(False)
+
+    # all-gather cost alone (reported, also part of the timed region above)
+    gather_ms = None
+    if world > 1:
+        fence()
+        g0 = time.perf_counter()
+        dist.all_gather_into_tensor(replay, traj)
+        torch.cuda.synchronize(device)
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        keys = sorted(totals)
+        s = torch.tensor([totals[k] for k in keys], dtype=torch.int64, device=device)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        job = {k: int(v) for k, v in zip(keys, s.tolist())}
+    else:
+        job = dict(totals)
+
+    if rank == 0:
+        games = job["games"]
+        steps_launched = max(totals["steps"], 1)
+        leaves_per_launch = totals["net_leaves"] / steps_launched          # this rank
+        # dominant kernel = largest share of sampled device time
+        shares = {k: v["avg_ms"] for k, v in prof.items()}
+        dom = max(FLOP_PER_LEAF, key=lambda k: shares.get(k, 0.0))
+        avg_ms = prof[dom]["avg_ms"]
+        achieved = (leaves_per_launch * FLOP_PER_LEAF[dom]) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        net_ms = sum(prof[k]["avg_ms"] for k in FLOP_PER_LEAF)
+        net_tflops = (leaves_per_launch * sum(FLOP_PER_LEAF.values())) / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0
+        plies_per_game = job["plies"] / max(games, 1)
+        depth_mean = job["depth_sum"] / max(job["sims"], 1)
+        tree_bytes_per_sim = 112.0 * depth_mean + 184.0
+        tree_ms = prof["tree_step"]["avg_ms"]
+        sims_per_launch = totals["sims"] / max(totals["steps"] + totals["moves_rounds"], 1)
+        tree_gbs = (sims_per_launch * tree_bytes_per_sim) / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
+        out = {
+            "metric": "selfplay_games_per_s",
+            "value": games / elapsed,
+            "unit": "games/s",
+            "sims_per_s": job["sims"] / elapsed,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic: games from the empty board, random-init Connect4Net (torch.manual_seed(0))",
+            "config": {"workload": f"{G} concurrent games per GPU x {args.sims} sims/move, batched leaf inference, "
+                                   "reference search rule (compat), every game played to the end",
+                       "games_per_gpu": G, "sims_per_move": args.sims, "c_puct": C_PUCT,
+                       "parallelism": f"games sharded over {world} GPU(s), no collective inside the search; "
+                                      "one all-gather of trajectories per round"},
+            "stats": {"games": games, "plies": job["plies"], "sims": job["sims"], "net_leaves": job["net_leaves"],
+                      "terminal_hits": job["terminal_hits"], "plies_per_game": plies_per_game,
+                      "mean_selection_depth": depth_mean,
+                      "leaf_batch_fill": job["net_leaves"] / max(job["steps"] * G, 1),
+                      "allgather_ms": gather_ms,
+                      "allgather_bytes": world * G * TRAJECTORY_BYTES if world > 1 else 0},
+            "kernel_ms": {k: round(v["avg_ms"], 4) for k, v in prof.items()},
+            "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                         "flop_per_leaf": FLOP_PER_LEAF[dom], "leaves_per_launch": leaves_per_launch,
+                         "avg_launch_ms": avg_ms, "whole_net_tflops": net_tflops},
+            "roofline_tree": {"kernel": "tree_step", "bound": "hbm", "achieved": tree_gbs, "peak": PEAK_HBM_GBS,
+                              "unit": "GB/s", "frac": tree_gbs / PEAK_HBM_GBS, "traffic": None,
+                              "bytes_per_sim": tree_bytes_per_sim, "avg_launch_ms": tree_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.sims, plies_per_game)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    engine.close()
+
+
+if __name__ == "__main__":
+    main()
