@@ -1,0 +1,112 @@
+"""The drop-in Python API (AlphaZeroAgent / self_play / run_tournament) on the GPU engine,
+against the golden vectors captured from the reference and the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    return torch
+
+
+def test_select_move_replays_golden_games(torch_mod, search_golden):
+    """The loop of train_alpha_zero.py:37-48 through the drop-in classes reproduces the reference's
+    moves and root visit counts ply by ply under the fixed evaluators."""
+    from nnbattle.agents.alphazero.utils import initialize_agent
+    from nnbattle.game import ConnectFourGame
+    for g in search_golden["games"]:
+        if g["sims"] > 200:
+            continue
+        agent = initialize_agent(action_dim=7, state_dim=2, use_gpu=False, num_simulations=g["sims"],
+                                 c_puct=g["c_puct"], load_model=False)
+        agent.evaluator = g["evaluator"]
+        game = ConnectFourGame()
+        game.reset()
+        agent.current_player = 1
+        moves, visits = [], []
+        while not game.is_terminal() and len(moves) < len(g["moves"]):
+            action, probs = agent.select_move(game)
+            assert probs.dtype == torch_mod.float32 and tuple(probs.shape) == (7,)
+            total = g["sims"] - 1
+            visits.append([int(round(float(p) * total)) for p in probs])
+            moves.append(action)
+            game.make_move(action)
+            agent.current_player = game.current_player
+        assert moves == g["moves"] and visits == g["visits"]
+        if g["complete"]:
+            assert game.get_result() == g["result"]
+
+
+def test_select_move_on_finished_game_returns_none(torch_mod):
+    from alphazero_amd.agent import initialize_agent
+    from alphazero_amd.game import ConnectFourGame
+    agent = initialize_agent(load_model=False, num_simulations=20)
+    agent.evaluator = "const"
+    game = ConnectFourGame()
+    for _ in range(4):
+        game.make_move(0)
+        game.current_player = 1
+    assert game.is_terminal()
+    assert agent.select_move(game) is None                       # agent_code.py:116-118
+    one = initialize_agent(load_model=False, num_simulations=1)
+    one.evaluator = "const"
+    with pytest.raises(ZeroDivisionError):                       # 0/0 visits, agent_code.py:229
+        one.select_move(ConnectFourGame())
+
+
+def test_batched_self_play_matches_reference_samples(torch_mod, search_golden):
+    from alphazero_amd.agent import initialize_agent
+    from alphazero_amd.selfplay import self_play
+    from oracle import ref_port as rp
+    g = next(x for x in search_golden["games"] if x["evaluator"] == "hash_q8" and x["sims"] == 100)
+    agent = initialize_agent(load_model=False, num_simulations=100)
+    agent.evaluator = "hash_q8"
+    memory = self_play(agent, 5)
+    assert len(memory) == 5 and len(agent.memory) == 5
+    final = rp.board_from_str(g["final_board"])
+    mover_after = 1 if len(g["moves"]) % 2 == 0 else 2
+    for planes, probs, result in memory:
+        assert result == g["result"]
+        assert (planes.cpu().numpy() == rp.planes(final, mover_after)).all()
+        assert float(probs.sum()) == 0.0 and tuple(probs.shape) == (7,)
+
+
+def test_net_agent_weight_refresh_and_real_net_game(torch_mod, net_golden_meta):
+    torch = torch_mod
+    from alphazero_amd.agent import initialize_agent
+    from alphazero_amd.game import ConnectFourGame
+    from oracle import ref_port as rp
+    torch.manual_seed(0)
+    agent = initialize_agent(load_model=False, num_simulations=100)      # seed-0 random init, as captured
+    g = net_golden_meta["game_s100"]
+    game = ConnectFourGame()
+    moves = []
+    for _ in range(4):
+        agent.current_player = game.current_player
+        a, probs = agent.select_move(game)
+        moves.append(a)
+        game.make_move(a)
+    assert moves == g["moves"][:4]
+    # new weights in agent.model must reach the engine without any explicit call
+    agent.model.load_state_dict(rp.seeded_state_dict(1))
+    game = ConnectFourGame()
+    agent.current_player = 1
+    a1, p1 = agent.select_move(game)
+    ev = rp.make_net_evaluator(rp.seeded_state_dict(1))
+    a_ref, v_ref = rp.compat_search(rp.new_board(), 1, 100, 1.4, ev)
+    assert a1 == a_ref and [int(round(float(p) * 99)) for p in p1] == v_ref
+
+
+def test_tournament_between_two_engine_agents(torch_mod, tmp_path):
+    from alphazero_amd.agent import initialize_agent
+    from alphazero_amd.tournament import run_tournament
+    a = initialize_agent(load_model=False, num_simulations=40)
+    b = initialize_agent(load_model=False, num_simulations=40)
+    a.evaluator, b.evaluator = "hash_q8", "hash_f32"
+    res = run_tournament([a, b], num_games=4, results_dir=str(tmp_path))
+    assert set(res) == {"AlphaZeroAgent_0", "AlphaZeroAgent_1", "draws"} and sum(res.values()) == 4
