@@ -41,6 +41,7 @@ FLOP_PER_LEAF = {
     "fc": 2 * 11520 * 1024,
     "heads": 2 * 1024 * 8,
 }
+DTYPE = "f32"
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X dense f32 matrix peak
 PEAK_HBM_GBS = 8000.0
 
@@ -170,6 +171,17 @@ def main():
         achieved = (leaves_per_launch * FLOP_PER_LEAF[dom]) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         net_ms = sum(prof[k]["avg_ms"] for k in FLOP_PER_LEAF)
         net_tflops = (leaves_per_launch * sum(FLOP_PER_LEAF.values())) / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0
+        traffic, traffic_src = None, None
+        try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes (collected offline)
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+            if files:
+                tj = json.load(open(files[-1]))
+                if tj.get("dtype", "f32") == DTYPE and G == GAMES_PER_GPU and args.sims == SIMS:
+                    traffic = tj["kernels"][dom]["hbm_bytes"]
+                    traffic_src = os.path.relpath(files[-1], ROOT)
+        except Exception:
+            traffic = None
         plies_per_game = job["plies"] / max(games, 1)
         depth_mean = job["depth_sum"] / max(job["sims"], 1)
         tree_bytes_per_sim = 112.0 * depth_mean + 184.0
@@ -188,7 +200,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": DTYPE,
             "data": "synthetic: games from the empty board, random-init Connect4Net (torch.manual_seed(0))",
             "config": {"workload": f"{G} concurrent games per GPU x {args.sims} sims/move, batched leaf inference, "
                                    "reference search rule (compat), every game played to the end",
@@ -203,7 +215,8 @@ def main():
                       "allgather_bytes": world * G * TRAJECTORY_BYTES if world > 1 else 0},
             "kernel_ms": {k: round(v["avg_ms"], 4) for k, v in prof.items()},
             "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "flop_per_leaf": FLOP_PER_LEAF[dom], "leaves_per_launch": leaves_per_launch,
                          "avg_launch_ms": avg_ms, "whole_net_tflops": net_tflops},
             "roofline_tree": {"kernel": "tree_step", "bound": "hbm", "achieved": tree_gbs, "peak": PEAK_HBM_GBS,
