@@ -26,7 +26,8 @@ class Config(C.Structure):
 
 class SearchParams(C.Structure):
     _fields_ = [("mode", C.c_int32), ("evaluator", C.c_int32), ("sims", C.c_int32),
-                ("weight_set", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32),
+                ("weight_set", C.c_int32), ("flags", C.c_int32), ("rng_move_index", C.c_int32),
+                ("rng_game_base", C.c_int32), ("reserved", C.c_int32),
                 ("c_puct", C.c_double), ("dirichlet_alpha", C.c_double),
                 ("dirichlet_eps", C.c_double), ("seed", C.c_uint64)]
 
@@ -57,8 +58,9 @@ SIGNATURES = {
     "nnb_ucb_scores": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_double, _P]),
     "nnb_net_forward": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P, _P, _P, _P, _P]),
     "nnb_net_forward_planes": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P, _P, _P]),
-    "nnb_search": (C.c_int, [_P, _P, C.POINTER(SearchParams), C.c_int32, _P, _P, _P, _P, _P,
+    "nnb_search": (C.c_int, [_P, _P, C.POINTER(SearchParams), C.c_int32, _P, _P, _P, _P, _P, _P,
                              C.POINTER(RoundStats)]),
+    "nnb_dirichlet_noise": (C.c_int, [_P, C.c_int32, C.c_uint64, _P, _P, _P, C.c_double, _P]),
     "nnb_selfplay_round": (C.c_int, [_P, _P, C.POINTER(SearchParams), C.c_int32, C.c_int32, _P, _P,
                                      _P, C.POINTER(RoundStats)]),
     "nnb_profile_enable": (C.c_int, [_P, C.c_int]),

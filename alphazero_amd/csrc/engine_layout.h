@@ -44,6 +44,9 @@ struct EngineDev {
     uint16_t *path;             // [G][kPathSlots] node indices root -> leaf of the pending leaf
     int32_t *ply;               // [G] plies played (self-play)
     int32_t *game_stats;        // [G][4]: depth_sum, terminal_hits, net_leaves, sims
+    int32_t *game_id;           // [G] global game index (RNG coordinate)
+    int32_t *move_index;        // [G] move index of the current search (RNG coordinate)
+    float   *root_noise;        // [G][7] Dirichlet noise mixed into the root priors (AZ)
 
     u64     *leaf_side;         // [G][2] side boards (me, opp) of the compacted leaf batch
     uint8_t *leaf_legal;        // [G]    legal mask of each batched leaf
@@ -60,6 +63,8 @@ struct SearchDev {
     int32_t evaluator;
     int32_t sims;
     int32_t flags;
+    int32_t rng_move_index;
+    int32_t rng_game_base;
     double  c_puct;
     double  dirichlet_alpha;
     double  dirichlet_eps;

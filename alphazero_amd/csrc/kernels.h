@@ -12,7 +12,7 @@ void launch_encode_planes(hipStream_t st, int n, const u64 *side, float *planes)
 void launch_ucb_scores(hipStream_t st, int n, const double *value, const int32_t *visits,
                        const int32_t *parent_visits, double c_puct, const double *log_table, int log_n,
                        double *out);
-void launch_tree_init(hipStream_t st, const EngineDev &e);
+void launch_tree_init(hipStream_t st, const EngineDev &e, const SearchDev &p, int make_noise, int selfplay);
 void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, int parity);
 hipError_t prepare_tree_fused(size_t lds_bytes);
 void launch_tree_fused(hipStream_t st, const EngineDev &e, const SearchDev &p, size_t lds_bytes);
@@ -20,7 +20,10 @@ void launch_readout(hipStream_t st, const EngineDev &e, const SearchDev &p, int3
                     int8_t *action_out, double *root_value_out, nnb_trajectory *traj, int selfplay);
 void launch_selfplay_init(hipStream_t st, const EngineDev &e, const u64 *start_boards,
                           const int8_t *start_players, nnb_trajectory *traj, int first_game_id);
-void launch_search_init(hipStream_t st, const EngineDev &e, const u64 *boards, const int8_t *players);
+void launch_search_init(hipStream_t st, const EngineDev &e, const u64 *boards, const int8_t *players,
+                        int game_base, const float *root_noise);
+void launch_dirichlet_noise(hipStream_t st, int n, u64 seed, const int32_t *game_ids, const int32_t *move_index,
+                            const uint8_t *legal, double alpha, float *out);
 void launch_stats_reduce(hipStream_t st, const EngineDev &e);
 void launch_fixed_eval(hipStream_t st, const EngineDev &e, const SearchDev &p, const int32_t *count_ptr);
 

@@ -98,6 +98,9 @@ void carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std::v
     d.path = c.take<uint16_t>(G * kPathSlots);
     d.ply = c.take<int32_t>(G);
     d.game_stats = c.take<int32_t>(4 * G);
+    d.game_id = c.take<int32_t>(G);
+    d.move_index = c.take<int32_t>(G);
+    d.root_noise = c.take<float>(7 * G);
     d.leaf_side = c.take<u64>(2 * G);
     d.leaf_legal = c.take<uint8_t>(G);
     d.leaf_count = c.take<int32_t>(64);
@@ -166,7 +169,7 @@ void prof_drain(nnb_engine *e) {          // call only when the stream is idle
 
 SearchDev to_dev(const nnb_search_params &p) {
     SearchDev s;
-    s.mode = p.mode; s.evaluator = p.evaluator; s.sims = p.sims; s.flags = p.flags;
+    s.mode = p.mode; s.evaluator = p.evaluator; s.sims = p.sims; s.flags = p.flags; s.rng_move_index = p.rng_move_index; s.rng_game_base = p.rng_game_base;
     s.c_puct = p.c_puct; s.dirichlet_alpha = p.dirichlet_alpha; s.dirichlet_eps = p.dirichlet_eps;
     s.seed = p.seed;
     return s;
@@ -179,10 +182,16 @@ int check_params(nnb_engine *e, const nnb_search_params *p, int n) {
         return fail(NNB_ERR_ARG, "n = %d out of range [1, max_games = %d]", n, e->cfg.max_games);
     if (p->sims < 1 || p->sims > e->cfg.max_sims)
         return fail(NNB_ERR_ARG, "sims = %d out of range [1, max_sims = %d]", p->sims, e->cfg.max_sims);
-    if (p->mode != NNB_MODE_COMPAT)
-        return fail(NNB_ERR_ARG, "mode %d is not supported by this build", p->mode);
-    if (p->evaluator < NNB_EVAL_NET || p->evaluator > NNB_EVAL_HASH_F32)
-        return fail(NNB_ERR_ARG, "evaluator %d is not supported by this build", p->evaluator);
+    if (p->mode != NNB_MODE_COMPAT && p->mode != NNB_MODE_AZ) return fail(NNB_ERR_ARG, "unknown mode %d", p->mode);
+    if (p->evaluator < NNB_EVAL_NET || p->evaluator > NNB_EVAL_ROLLOUT)
+        return fail(NNB_ERR_ARG, "unknown evaluator %d", p->evaluator);
+    if (p->evaluator == NNB_EVAL_ROLLOUT && (p->flags & NNB_FLAG_LOCKSTEP))
+        return fail(NNB_ERR_ARG, "the rollout evaluator runs in the fused kernel only (no NNB_FLAG_LOCKSTEP)");
+    if (p->mode == NNB_MODE_AZ) {
+        if (!(p->dirichlet_eps >= 0.0 && p->dirichlet_eps <= 1.0)) return fail(NNB_ERR_ARG, "dirichlet_eps must be in [0, 1]");
+        if (!(p->dirichlet_alpha >= 0.0) || !std::isfinite(p->dirichlet_alpha))
+            return fail(NNB_ERR_ARG, "dirichlet_alpha must be finite and >= 0");
+    }
     if (p->evaluator == NNB_EVAL_NET) {
         if (p->weight_set < 0 || p->weight_set >= e->cfg.n_weight_sets)
             return fail(NNB_ERR_ARG, "weight_set %d out of range", p->weight_set);
@@ -207,12 +216,19 @@ void forward_leaves(nnb_engine *e, hipStream_t st, int weight_set, const int32_t
 // One move for every live game: S simulations, then the root readout.
 int run_move(nnb_engine *e, hipStream_t st, const nnb_search_params &p, int32_t *visits_out,
              int8_t *action_out, double *root_value_out, nnb_trajectory *traj, int selfplay,
-             long long *steps) {
-    const SearchDev sd = to_dev(p);
+             bool noise_given, long long *steps) {
+    SearchDev sd = to_dev(p);
     const EngineDev &d = e->dev;
     e->prof_stride = p.sims / kProfSamples + 1;
+    const bool az = p.mode == NNB_MODE_AZ;
+    if (!az) { sd.dirichlet_eps = 0.0; sd.dirichlet_alpha = 0.0; }
+    int make_noise = 0;
+    if (az && sd.dirichlet_eps > 0.0 && !noise_given) {
+        if (!(sd.dirichlet_alpha > 0.0)) return fail(NNB_ERR_ARG, "dirichlet_eps > 0 needs dirichlet_alpha > 0 or root_noise");
+        make_noise = 1;
+    }
+    launch_tree_init(st, d, sd, make_noise, selfplay);
     if (p.evaluator == NNB_EVAL_NET || (p.flags & NNB_FLAG_LOCKSTEP)) {
-        launch_tree_init(st, d);
         for (int s = 0; s <= p.sims; ++s) {
             { ProfScope ps(e, 0, st); launch_tree_step(st, d, sd, s & 1); }
             if (s == p.sims) break;
@@ -221,7 +237,8 @@ int run_move(nnb_engine *e, hipStream_t st, const nnb_search_params &p, int32_t 
         }
         *steps += p.sims;
     } else {
-        size_t lds = (size_t)d.pool_cap * sizeof(Node) + (size_t)(p.sims + 2) * sizeof(double);
+        size_t lds = (size_t)d.pool_cap * sizeof(Node) +
+                     (az ? (size_t)d.pool_cap * sizeof(float) : (size_t)(p.sims + 2) * sizeof(double));
         if (lds > 160 * 1024)
             return fail(NNB_ERR_ARG, "sims = %d needs %zu bytes of LDS for the fused tree kernel (limit 163840)",
                         p.sims, lds);
@@ -405,16 +422,17 @@ int nnb_net_forward_planes(nnb_engine *e, int weight_set, void *stream, int32_t 
 }
 
 int nnb_search(nnb_engine *e, void *stream, const nnb_search_params *params, int32_t n,
-               const uint64_t *root_colour_boards, const int8_t *root_players, int32_t *visits_out,
-               int8_t *action_out, double *root_value_out, nnb_round_stats *stats_out) {
+               const uint64_t *root_colour_boards, const int8_t *root_players, const float *root_noise,
+               int32_t *visits_out, int8_t *action_out, double *root_value_out, nnb_round_stats *stats_out) {
     int rc = check_params(e, params, n);
     if (rc) return rc;
     if (!root_colour_boards || !root_players) return fail(NNB_ERR_ARG, "root boards / players is null");
     hipStream_t st = static_cast<hipStream_t>(stream);
     e->dev.n_games = n;
-    launch_search_init(st, e->dev, reinterpret_cast<const u64 *>(root_colour_boards), root_players);
+    launch_search_init(st, e->dev, reinterpret_cast<const u64 *>(root_colour_boards), root_players,
+                       params->rng_game_base, root_noise);
     long long steps = 0;
-    rc = run_move(e, st, *params, visits_out, action_out, root_value_out, nullptr, 0, &steps);
+    rc = run_move(e, st, *params, visits_out, action_out, root_value_out, nullptr, 0, root_noise != nullptr, &steps);
     if (rc) return rc;
     return collect_stats(e, st, stats_out, steps, 1, n);
 }
@@ -438,7 +456,7 @@ int nnb_selfplay_round(nnb_engine *e, void *stream, const nnb_search_params *par
     int live = e->host_counters[0];
     while (live > 0 && rounds < kMaxPlies + 1) {
         HIP_TRY(hipMemsetAsync(e->dev.counters, 0, 16 * sizeof(int32_t), st));
-        rc = run_move(e, st, *params, nullptr, nullptr, nullptr, trajectories_out, 1, &steps);
+        rc = run_move(e, st, *params, nullptr, nullptr, nullptr, trajectories_out, 1, false, &steps);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(e->host_counters, e->dev.counters, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -447,6 +465,18 @@ int nnb_selfplay_round(nnb_engine *e, void *stream, const nnb_search_params *par
         ++rounds;
     }
     return collect_stats(e, st, stats_out, steps, rounds, n_games);
+}
+
+int nnb_dirichlet_noise(void *stream, int32_t n, uint64_t seed, const int32_t *game_ids, const int32_t *move_indices,
+                        const uint8_t *legal_masks, double alpha, float *noise_out) {
+    if (n < 0) return fail(NNB_ERR_ARG, "n < 0");
+    if (n == 0) return NNB_OK;
+    if (!game_ids || !move_indices || !legal_masks || !noise_out) return fail(NNB_ERR_ARG, "null pointer");
+    if (!(alpha > 0.0) || !std::isfinite(alpha)) return fail(NNB_ERR_ARG, "alpha must be finite and > 0");
+    launch_dirichlet_noise(static_cast<hipStream_t>(stream), n, seed, game_ids, move_indices, legal_masks, alpha,
+                           noise_out);
+    HIP_TRY(hipGetLastError());
+    return NNB_OK;
 }
 
 int nnb_profile_enable(nnb_engine *e, int on) {

@@ -162,33 +162,240 @@ __device__ __forceinline__ double fixed_eval(int evaluator, u64 me, u64 opp) {
 }
 
 // ---------------------------------------------------------------------------
-// Start of a move: every live game gets a fresh tree whose root has visits = 1
-// (agent_code.py:159-160).
+// Counter-based RNG (Philox4x32-10): integer only, so the CPU restatement reproduces
+// every draw.  Counter = (game id, move index, stream, block), key = seed.
 // ---------------------------------------------------------------------------
-__global__ void tree_init_kernel(EngineDev e) {
+struct U32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ U32x4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                            uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return {c0, c1, c2, c3};
+}
+
+// ROLLOUT evaluator: uniformly random playout to the end, one Philox word per ply
+// (stream = simulation index).  Returns c4::result() of the final position.
+__device__ __forceinline__ int rollout(u64 b1, u64 b2, int mover, u64 seed, uint32_t game, uint32_t move,
+                                       uint32_t sim) {
+    U32x4 rnd = {0, 0, 0, 0};
+    for (int rp = 0; rp < 42; ++rp) {
+        if (c4::is_terminal(b1, b2)) break;
+        unsigned legal = c4::legal_mask(b1 | b2);
+        if (!legal) break;
+        if ((rp & 3) == 0) rnd = philox4x32(game, move, sim, (uint32_t)(rp >> 2), (uint32_t)seed, (uint32_t)(seed >> 32));
+        uint32_t word = (rp & 3) == 0 ? rnd.x : ((rp & 3) == 1 ? rnd.y : ((rp & 3) == 2 ? rnd.z : rnd.w));
+        int idx = (int)(((uint64_t)word * (uint64_t)__popc(legal)) >> 32);
+        unsigned m = legal;
+        for (int k = 0; k < idx; ++k) m &= m - 1;
+        u64 cell = c4::drop_cell(b1 | b2, __ffs(m) - 1);
+        if (mover == 1) b1 |= cell; else b2 |= cell;
+        mover = 3 - mover;
+    }
+    return c4::result(b1, b2);
+}
+
+// Priors of the fixed evaluators for column `col`: uniform over the legal columns, or
+// weights 1 + byte_col of the position hash, normalised in float32 in ascending order.
+__device__ __forceinline__ float fixed_prior(int evaluator, u64 me, u64 opp, unsigned legal, int col) {
+    if (evaluator == NNB_EVAL_HASH_Q8 || evaluator == NNB_EVAL_HASH_F32) {
+        u64 h = c4::mix64(me, opp);
+        float sum = 0.0f, mine = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 7; ++a) {
+            float w = ((legal >> a) & 1) ? (float)(1 + (int)((h >> (8 * a)) & 0xFF)) : 0.0f;
+            sum += w;
+            if (a == col) mine = w;
+        }
+        return mine / sum;
+    }
+    return (col < 7 && ((legal >> col) & 1)) ? (float)(1.0 / (double)__popc(legal)) : 0.0f;
+}
+
+// Dirichlet(alpha) over the legal columns: Marsaglia-Tsang gamma variates from Philox
+// uniforms (stream 0xD1D1D1D1), normalised.  out[c] = 0 for illegal columns.
+struct NoiseRng {
+    uint32_t game, move, block; u64 seed; U32x4 buf; int have;
+    __device__ double uniform() {           // (0,1), 53 bits
+        if (have == 0) { buf = philox4x32(game, move, 0xD1D1D1D1u, block++, (uint32_t)seed, (uint32_t)(seed >> 32)); have = 2; }
+        uint32_t a = have == 2 ? buf.x : buf.z, b = have == 2 ? buf.y : buf.w;
+        --have;
+        return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6) + 0.5) / 9007199254740992.0;
+    }
+    __device__ double normal() {
+        double u1 = uniform(), u2 = uniform();
+        return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    }
+    __device__ double gamma(double alpha) {
+        double boost = 1.0;
+        if (alpha < 1.0) { boost = pow(uniform(), 1.0 / alpha); alpha += 1.0; }
+        const double d = alpha - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+        for (int tries = 0; tries < 64; ++tries) {
+            double x = normal(), v = 1.0 + c * x;
+            if (v <= 0.0) continue;
+            v = v * v * v;
+            double u = uniform();
+            if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) return d * v * boost;
+        }
+        return d * boost;
+    }
+};
+
+__device__ void dirichlet_noise(u64 seed, uint32_t game, uint32_t move, unsigned legal, double alpha, float *out) {
+    NoiseRng rng{game, move, 0, seed, {0, 0, 0, 0}, 0};
+    double gsum = 0.0, gv[7];
+    for (int c = 0; c < 7; ++c) {
+        gv[c] = ((legal >> c) & 1) ? rng.gamma(alpha) : 0.0;
+        gsum += gv[c];
+    }
+    const int nl = __popc(legal);
+    for (int c = 0; c < 7; ++c)
+        out[c] = gsum > 0.0 ? (float)(gv[c] / gsum) : (((legal >> c) & 1) ? (float)(1.0 / nl) : 0.0f);
+}
+
+__global__ void dirichlet_noise_kernel(int n, u64 seed, const int32_t *__restrict__ game_ids,
+                                       const int32_t *__restrict__ move_index, const uint8_t *__restrict__ legal,
+                                       double alpha, float *__restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dirichlet_noise(seed, (uint32_t)game_ids[i], (uint32_t)move_index[i], legal[i], alpha, out + 7 * i);
+}
+
+// ---------------------------------------------------------------------------
+// PUCT ("AZ") primitives.  W of a node is the value sum seen by the player who moved
+// into it, so a parent maximises Q = W/N directly.
+// ---------------------------------------------------------------------------
+struct DescentAz {
+    u64 c1, c2;
+    int node, len, mover;   // mover = side to move at the leaf
+    bool terminal;
+};
+
+__device__ __forceinline__ DescentAz descend_az(const Node *pool, const float *prior, double c_puct, int player,
+                                                u64 c1, u64 c2, int lane, int &mypath) {
+    DescentAz r;
+    Node root = pool[0];
+    int cur_visits = root.visits, first = root.first_child, nch = root.nchild;
+    r.node = 0; r.len = 1; r.mover = player; mypath = 0;
+    r.terminal = c4::is_terminal(c1, c2);
+    while (nch > 0 && !r.terminal) {
+        const bool in = lane < nch;
+        const int ci = first + (in ? lane : 0);
+        Node ch = pool[ci];
+        const double n = (double)ch.visits;
+        const double q = ch.visits > 0 ? ch.value / n : 0.0;
+        const double u = c_puct * (double)prior[ci] * sqrt((double)cur_visits) / (1.0 + n);
+        double score = q + u;
+        if (!in) score = -INFINITY;
+        int best = lane;
+#pragma unroll
+        for (int off = 4; off >= 1; off >>= 1) {
+            double os = __shfl_xor(score, off);
+            int ob = __shfl_xor(best, off);
+            bool take = (os > score) || (os == score && ob < best);
+            score = take ? os : score;
+            best = take ? ob : best;
+        }
+        best = __shfl(best, 0);
+        int a = __shfl((int)ch.action, best);
+        cur_visits = __shfl(ch.visits, best);
+        int nfirst = __shfl((int)ch.first_child, best);
+        int nn = __shfl((int)ch.nchild, best);
+        r.node = first + best;
+        first = nfirst; nch = nn;
+        u64 cell = c4::drop_cell(c1 | c2, a);
+        if (r.mover == 1) c1 |= cell; else c2 |= cell;
+        r.mover = 3 - r.mover;
+        if (lane == r.len) mypath = r.node;
+        ++r.len;
+        r.terminal = c4::is_terminal(c1, c2);
+    }
+    r.c1 = c1; r.c2 = c2;
+    return r;
+}
+
+// Children with priors; `pr` is the prior of column `lane` (lanes 0..6).
+__device__ __forceinline__ int expand_az(Node *pool, float *prior, int node, int n_nodes, unsigned legal, float pr,
+                                         int lane) {
+    const int nlegal = __popc(legal);
+    unsigned m = legal;
+    for (int k = 0; k < lane && k < 7; ++k) m &= m - 1;
+    const int col = m ? __ffs(m) - 1 : 0;
+    const float pc = __shfl(pr, col);
+    if (lane < nlegal) {
+        Node c;
+        c.value = 0.0; c.visits = 0; c.first_child = 0; c.nchild = 0; c.action = (uint8_t)col;
+        pool[n_nodes + lane] = c;
+        prior[n_nodes + lane] = pc;
+    }
+    if (lane == 0) {
+        pool[node].first_child = (uint16_t)n_nodes;
+        pool[node].nchild = (uint8_t)nlegal;
+    }
+    return nlegal;
+}
+
+// v = value for the side to move at the leaf; the leaf gets -v, its parent +v, ...
+__device__ __forceinline__ void backup_az(Node *pool, int mypath, int len, double v, int lane) {
+    if (lane < len) {
+        Node *n = pool + mypath;
+        n->visits += 1;
+        n->value += ((len - 1 - lane) & 1) ? v : -v;
+    }
+}
+
+// value of a leaf for the side to move, fixed evaluators (AZ frame)
+__device__ __forceinline__ double fixed_eval_az(const SearchDev &p, u64 c1, u64 c2, int mover, uint32_t game,
+                                                uint32_t move, uint32_t sim) {
+    if (p.evaluator == NNB_EVAL_ROLLOUT) {
+        int res = rollout(c1, c2, mover, p.seed, game, move, sim);
+        return (res == 2 || res == 0) ? 0.0 : ((res == 1) == (mover == 1) ? 1.0 : -1.0);
+    }
+    return fixed_eval(p.evaluator, mover == 1 ? c1 : c2, mover == 1 ? c2 : c1);
+}
+
+// ---------------------------------------------------------------------------
+// Start of a move: every live game gets a fresh tree.  COMPAT: root.visits = 1
+// (agent_code.py:159-160).  AZ: root.visits = 0 and, when alpha > 0, fresh Dirichlet
+// noise for the root unless the caller supplied it.
+// ---------------------------------------------------------------------------
+__global__ void tree_init_kernel(EngineDev e, SearchDev p, int make_noise, int selfplay) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g == 0) { e.leaf_count[0] = 0; e.leaf_count[1] = 0; }
     if (g >= e.n_games) return;
     if (!e.active[g]) return;
     Node r;
-    r.value = 0.0; r.visits = 1; r.first_child = 0; r.nchild = 0; r.action = 0xFF;
+    r.value = 0.0; r.visits = p.mode == NNB_MODE_AZ ? 0 : 1; r.first_child = 0; r.nchild = 0; r.action = 0xFF;
     e.nodes[(size_t)g * e.pool_cap] = r;
     e.n_nodes[g] = 1;
     e.sims_done[g] = 0;
     e.pending[g] = -1;
     e.path_len[g] = 0;
+    e.move_index[g] = selfplay ? e.ply[g] : p.rng_move_index;
+    if (make_noise) {
+        unsigned legal = c4::legal_mask(e.root_boards[2 * g] | e.root_boards[2 * g + 1]);
+        dirichlet_noise(p.seed, (uint32_t)e.game_id[g], (uint32_t)e.move_index[g], legal, p.dirichlet_alpha,
+                        e.root_noise + 7 * g);
+    }
 }
 
 // ---------------------------------------------------------------------------
-// K2, lock-step form (NET evaluator): one launch per simulation round.
-//   1. back up the value the network produced for this game's pending leaf;
-//   2. run simulations until one needs the network (a non-terminal leaf) or the
-//      budget is used up; terminal leaves are backed up on the spot
-//      (agent_code.py:182-186);
-//   3. expand the leaf, append its side boards to the compacted leaf batch and
-//      remember the path for step 1 of the next launch.
-// Launch with 256 threads = 4 games per block.
+// K2, lock-step form: one launch per simulation round.
+//   1. consume the evaluator's output for this game's pending leaf: (AZ) expand the leaf
+//      with its priors, then back the value up the stored path;
+//   2. run simulations until one needs the evaluator (a non-terminal leaf) or the budget
+//      is used up; terminal leaves are backed up on the spot (agent_code.py:182-186);
+//   3. (COMPAT) expand the leaf - the reference ignores priors; append the leaf's side
+//      boards to the compacted batch and remember the path for step 1 of the next launch.
+// Launch with 256 threads = 4 games per block, one wavefront per game.
 // ---------------------------------------------------------------------------
+template <bool AZ>
 __global__ __launch_bounds__(256) void tree_step_kernel(EngineDev e, SearchDev p, int parity) {
     const int lane = threadIdx.x & 63;
     const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -197,6 +404,7 @@ __global__ __launch_bounds__(256) void tree_step_kernel(EngineDev e, SearchDev p
     if (!e.active[g]) return;
 
     Node *pool = e.nodes + (size_t)g * e.pool_cap;
+    float *prior = e.prior + (size_t)g * e.pool_cap;
     int sims_done = e.sims_done[g];
     int n_nodes = e.n_nodes[g];
     const int player = e.root_player[g];
@@ -208,35 +416,60 @@ __global__ __launch_bounds__(256) void tree_step_kernel(EngineDev e, SearchDev p
         int len = e.path_len[g];
         int mypath = e.path[g * kPathSlots + lane];
         double v = (double)e.leaf_value[pend];           // value.item(), agent_code.py:213
-        backup_path(pool, mypath, len, v, lane);
+        if (AZ) {
+            const int leaf = __shfl(mypath, len - 1);
+            const unsigned legal = e.leaf_legal[pend];
+            float pr = lane < 7 ? e.leaf_prior[pend * 7 + lane] : 0.0f;
+            if (len == 1 && p.dirichlet_eps > 0.0 && lane < 7)
+                pr = (float)((1.0 - p.dirichlet_eps) * (double)pr + p.dirichlet_eps * (double)e.root_noise[7 * g + lane]);
+            n_nodes += expand_az(pool, prior, leaf, n_nodes, legal, pr, lane);
+            backup_az(pool, mypath, len, v, lane);
+        } else {
+            backup_path(pool, mypath, len, v, lane);
+        }
         wave_mem_sync();
         ++sims_done;
         pend = -1;
     }
 
     while (sims_done < p.sims) {
-        int mypath;
-        Descent d = descend_compat(pool, e.log_table, p.c_puct, player, r1, r2, lane, mypath);
-        depth_sum += d.len - 1;
-        unsigned legal = c4::legal_mask(d.c1 | d.c2);
-        if (d.terminal || legal == 0) {
-            // agent_code.py:182-186 and :190-193
-            double v = d.terminal ? c4::reward(d.c1, d.c2) : 0.0;
-            backup_path(pool, mypath, d.len, v, lane);
+        int mypath, len, node;
+        u64 c1, c2;
+        bool terminal;
+        int mover = player;
+        if (AZ) {
+            DescentAz d = descend_az(pool, prior, p.c_puct, player, r1, r2, lane, mypath);
+            c1 = d.c1; c2 = d.c2; len = d.len; node = d.node; terminal = d.terminal; mover = d.mover;
+        } else {
+            Descent d = descend_compat(pool, e.log_table, p.c_puct, player, r1, r2, lane, mypath);
+            c1 = d.c1; c2 = d.c2; len = d.len; node = d.node; terminal = d.terminal;
+        }
+        depth_sum += len - 1;
+        unsigned legal = c4::legal_mask(c1 | c2);
+        if (terminal || legal == 0) {
+            if (AZ) {
+                double v = (c4::has_four(c1) || c4::has_four(c2)) ? -1.0 : 0.0;
+                backup_az(pool, mypath, len, v, lane);
+            } else {
+                // agent_code.py:182-186 and :190-193
+                double v = terminal ? c4::reward(c1, c2) : 0.0;
+                backup_path(pool, mypath, len, v, lane);
+            }
             wave_mem_sync();
             ++sims_done; ++term_hits;
             continue;
         }
-        n_nodes += expand_compat(pool, d.node, n_nodes, legal, lane);
+        if (!AZ) n_nodes += expand_compat(pool, node, n_nodes, legal, lane);
         int slot = 0;
         if (lane == 0) slot = atomicAdd(&e.leaf_count[parity], 1);
         slot = __shfl(slot, 0);
         if (lane == 0) {
-            // the leaf is encoded from the root mover's side at every depth (agent_code.py:85)
-            e.leaf_side[2 * slot] = player == 1 ? d.c1 : d.c2;
-            e.leaf_side[2 * slot + 1] = player == 1 ? d.c2 : d.c1;
+            // COMPAT: the leaf is encoded from the root mover's side at every depth
+            // (agent_code.py:85); AZ: from the side to move at the leaf
+            e.leaf_side[2 * slot] = mover == 1 ? c1 : c2;
+            e.leaf_side[2 * slot + 1] = mover == 1 ? c2 : c1;
             e.leaf_legal[slot] = (uint8_t)legal;
-            e.path_len[g] = d.len;
+            e.path_len[g] = len;
         }
         e.path[g * kPathSlots + lane] = (uint16_t)mypath;
         pend = slot;
@@ -254,10 +487,12 @@ __global__ __launch_bounds__(256) void tree_step_kernel(EngineDev e, SearchDev p
 }
 
 // ---------------------------------------------------------------------------
-// K2, fused form (CONST / HASH evaluators): the whole search of one move in one
-// launch, node pool and log table resident in LDS.  One 64-thread block per game.
-// Dynamic LDS: pool_cap*16 bytes of nodes followed by (sims+2) doubles.
+// K2, fused form (fixed evaluators: CONST / HASH / ROLLOUT): the whole search of one move
+// in one launch, the node pool resident in LDS.  One 64-thread block (one wavefront) per
+// game.  Dynamic LDS: pool_cap*16 bytes of nodes, then (COMPAT) the log table of sims+2
+// doubles or (AZ) pool_cap float priors.
 // ---------------------------------------------------------------------------
+template <bool AZ>
 __global__ __launch_bounds__(64) void tree_fused_kernel(EngineDev e, SearchDev p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -266,32 +501,61 @@ __global__ __launch_bounds__(64) void tree_fused_kernel(EngineDev e, SearchDev p
     if (!e.active[g]) return;
     Node *pool = reinterpret_cast<Node *>(smem);
     double *logt = reinterpret_cast<double *>(smem + (size_t)e.pool_cap * sizeof(Node));
-    for (int i = lane; i < p.sims + 2; i += 64) logt[i] = e.log_table[i];
+    float *prior = reinterpret_cast<float *>(smem + (size_t)e.pool_cap * sizeof(Node));
+    if (!AZ)
+        for (int i = lane; i < p.sims + 2; i += 64) logt[i] = e.log_table[i];
     if (lane == 0) {
         Node r;
-        r.value = 0.0; r.visits = 1; r.first_child = 0; r.nchild = 0; r.action = 0xFF;
+        r.value = 0.0; r.visits = AZ ? 0 : 1; r.first_child = 0; r.nchild = 0; r.action = 0xFF;
         pool[0] = r;
     }
     __syncthreads();
 
     const int player = e.root_player[g];
     const u64 r1 = e.root_boards[2 * g], r2 = e.root_boards[2 * g + 1];
+    const uint32_t game = (uint32_t)e.game_id[g], move = (uint32_t)e.move_index[g];
     int n_nodes = 1, depth_sum = 0, term_hits = 0, leaves = 0;
     for (int s = 0; s < p.sims; ++s) {
         int mypath;
-        Descent d = descend_compat(pool, logt, p.c_puct, player, r1, r2, lane, mypath);
-        depth_sum += d.len - 1;
-        unsigned legal = c4::legal_mask(d.c1 | d.c2);
-        double v;
-        if (d.terminal || legal == 0) {
-            v = d.terminal ? c4::reward(d.c1, d.c2) : 0.0;
-            ++term_hits;
+        if (AZ) {
+            DescentAz d = descend_az(pool, prior, p.c_puct, player, r1, r2, lane, mypath);
+            depth_sum += d.len - 1;
+            unsigned legal = c4::legal_mask(d.c1 | d.c2);
+            double v;
+            if (d.terminal || legal == 0) {
+                v = (c4::has_four(d.c1) || c4::has_four(d.c2)) ? -1.0 : 0.0;
+                ++term_hits;
+            } else {
+                const u64 me = d.mover == 1 ? d.c1 : d.c2, opp = d.mover == 1 ? d.c2 : d.c1;
+                float pr = lane < 7 ? fixed_prior(p.evaluator, me, opp, legal, lane) : 0.0f;
+                if (d.len == 1 && p.dirichlet_eps > 0.0 && lane < 7)
+                    pr = (float)((1.0 - p.dirichlet_eps) * (double)pr + p.dirichlet_eps * (double)e.root_noise[7 * g + lane]);
+                n_nodes += expand_az(pool, prior, d.node, n_nodes, legal, pr, lane);
+                v = fixed_eval_az(p, d.c1, d.c2, d.mover, game, move, (uint32_t)s);
+                ++leaves;
+            }
+            backup_az(pool, mypath, d.len, v, lane);
         } else {
-            n_nodes += expand_compat(pool, d.node, n_nodes, legal, lane);
-            v = fixed_eval(p.evaluator, player == 1 ? d.c1 : d.c2, player == 1 ? d.c2 : d.c1);
-            ++leaves;
+            Descent d = descend_compat(pool, logt, p.c_puct, player, r1, r2, lane, mypath);
+            depth_sum += d.len - 1;
+            unsigned legal = c4::legal_mask(d.c1 | d.c2);
+            double v;
+            if (d.terminal || legal == 0) {
+                v = d.terminal ? c4::reward(d.c1, d.c2) : 0.0;
+                ++term_hits;
+            } else {
+                n_nodes += expand_compat(pool, d.node, n_nodes, legal, lane);
+                if (p.evaluator == NNB_EVAL_ROLLOUT) {
+                    // playout value in get_reward()'s absolute frame, root mover moving first
+                    int res = rollout(d.c1, d.c2, player, p.seed, game, move, (uint32_t)s);
+                    v = res == 1 ? -1.0 : (res == -1 ? 1.0 : 0.0);
+                } else {
+                    v = fixed_eval(p.evaluator, player == 1 ? d.c1 : d.c2, player == 1 ? d.c2 : d.c1);
+                }
+                ++leaves;
+            }
+            backup_path(pool, mypath, d.len, v, lane);
         }
-        backup_path(pool, mypath, d.len, v, lane);
         __syncthreads();
     }
     // hand the root and its children to the readout kernel through the global pool
@@ -376,6 +640,7 @@ __global__ void selfplay_init_kernel(EngineDev e, const u64 *__restrict__ start_
     e.root_boards[2 * g] = b1; e.root_boards[2 * g + 1] = b2;
     e.root_player[g] = (int8_t)player;
     e.ply[g] = 0;
+    e.game_id[g] = first_game_id + g;
     for (int k = 0; k < 4; ++k) e.game_stats[4 * g + k] = 0;
     nnb_trajectory *t = traj + g;
     t->length = 0; t->result = 2; t->game_id = first_game_id + g; t->reserved = 0;
@@ -388,13 +653,17 @@ __global__ void selfplay_init_kernel(EngineDev e, const u64 *__restrict__ start_
 
 // Search-only set-up: caller-supplied roots, every root searched.
 __global__ void search_init_kernel(EngineDev e, const u64 *__restrict__ boards,
-                                   const int8_t *__restrict__ players) {
+                                   const int8_t *__restrict__ players, int game_base,
+                                   const float *__restrict__ root_noise) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= e.n_games) return;
     e.root_boards[2 * g] = boards[2 * g]; e.root_boards[2 * g + 1] = boards[2 * g + 1];
     e.root_player[g] = players[g];
     e.active[g] = 1;
     e.ply[g] = 0;
+    e.game_id[g] = game_base + g;
+    if (root_noise)
+        for (int c = 0; c < 7; ++c) e.root_noise[7 * g + c] = root_noise[7 * g + c];
     for (int k = 0; k < 4; ++k) e.game_stats[4 * g + k] = 0;
 }
 
@@ -420,7 +689,12 @@ __global__ void stats_reduce_kernel(EngineDev e) {
 __global__ void fixed_eval_kernel(EngineDev e, SearchDev p, const int32_t *__restrict__ count_ptr) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= *count_ptr) return;
-    e.leaf_value[i] = (float)fixed_eval(p.evaluator, e.leaf_side[2 * i], e.leaf_side[2 * i + 1]);
+    const u64 me = e.leaf_side[2 * i], opp = e.leaf_side[2 * i + 1];
+    e.leaf_value[i] = (float)fixed_eval(p.evaluator, me, opp);
+    if (p.mode == NNB_MODE_AZ) {
+        const unsigned legal = e.leaf_legal[i];
+        for (int c = 0; c < 7; ++c) e.leaf_prior[7 * i + c] = fixed_prior(p.evaluator, me, opp, legal, c);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -447,21 +721,32 @@ void launch_ucb_scores(hipStream_t st, int n, const double *value, const int32_t
                                                     log_n, out);
 }
 
-void launch_tree_init(hipStream_t st, const EngineDev &e) {
-    tree_init_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e);
+void launch_tree_init(hipStream_t st, const EngineDev &e, const SearchDev &p, int make_noise, int selfplay) {
+    tree_init_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, p, make_noise, selfplay);
 }
 
 void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, int parity) {
-    tree_step_kernel<<<cdiv(e.n_games, 4), 256, 0, st>>>(e, p, parity);
+    if (p.mode == NNB_MODE_AZ) tree_step_kernel<true><<<cdiv(e.n_games, 4), 256, 0, st>>>(e, p, parity);
+    else tree_step_kernel<false><<<cdiv(e.n_games, 4), 256, 0, st>>>(e, p, parity);
 }
 
 hipError_t prepare_tree_fused(size_t lds_bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(tree_fused_kernel),
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(tree_fused_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (err != hipSuccess) return err;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(tree_fused_kernel<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 }
 
 void launch_tree_fused(hipStream_t st, const EngineDev &e, const SearchDev &p, size_t lds_bytes) {
-    tree_fused_kernel<<<e.n_games, 64, lds_bytes, st>>>(e, p);
+    if (p.mode == NNB_MODE_AZ) tree_fused_kernel<true><<<e.n_games, 64, lds_bytes, st>>>(e, p);
+    else tree_fused_kernel<false><<<e.n_games, 64, lds_bytes, st>>>(e, p);
+}
+
+void launch_dirichlet_noise(hipStream_t st, int n, u64 seed, const int32_t *game_ids, const int32_t *move_index,
+                            const uint8_t *legal, double alpha, float *out) {
+    if (n <= 0) return;
+    dirichlet_noise_kernel<<<cdiv(n, 64), 64, 0, st>>>(n, seed, game_ids, move_index, legal, alpha, out);
 }
 
 void launch_readout(hipStream_t st, const EngineDev &e, const SearchDev &p, int32_t *visits_out,
@@ -476,8 +761,9 @@ void launch_selfplay_init(hipStream_t st, const EngineDev &e, const u64 *start_b
                                                                first_game_id);
 }
 
-void launch_search_init(hipStream_t st, const EngineDev &e, const u64 *boards, const int8_t *players) {
-    search_init_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, boards, players);
+void launch_search_init(hipStream_t st, const EngineDev &e, const u64 *boards, const int8_t *players,
+                        int game_base, const float *root_noise) {
+    search_init_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, boards, players, game_base, root_noise);
 }
 
 void launch_fixed_eval(hipStream_t st, const EngineDev &e, const SearchDev &p, const int32_t *count_ptr) {

@@ -92,12 +92,12 @@ class Engine:
 
     def params(self, sims: int, c_puct: float = 1.4, evaluator="net", mode="compat", weight_set: int = 0,
                dirichlet_alpha: float = 0.0, dirichlet_eps: float = 0.0, seed: int = 0,
-               lockstep: bool = False) -> SearchParams:
+               lockstep: bool = False, rng_move_index: int = 0, rng_game_base: int = 0) -> SearchParams:
         ev = EVALUATORS[evaluator] if isinstance(evaluator, str) else int(evaluator)
         md = MODES[mode] if isinstance(mode, str) else int(mode)
-        return SearchParams(md, ev, int(sims), int(weight_set), int(bool(lockstep)), 0, float(c_puct),
-                            float(dirichlet_alpha),
-                            float(dirichlet_eps), int(seed))
+        return SearchParams(md, ev, int(sims), int(weight_set), int(bool(lockstep)), int(rng_move_index),
+                            int(rng_game_base), 0, float(c_puct), float(dirichlet_alpha), float(dirichlet_eps),
+                            int(seed))
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state_dict, weight_set: int = 0):
@@ -179,8 +179,9 @@ class Engine:
         return logp, value
 
     # ------------------------------------------------------------------ K2 / K7
-    def search(self, colour_boards, players, params: SearchParams):
-        """One search per root.  Returns (visits int32[n,7], action int8[n], root_value f64[n], stats)."""
+    def search(self, colour_boards, players, params: SearchParams, root_noise=None):
+        """One search per root.  Returns (visits int32[n,7], action int8[n], root_value f64[n], stats).
+        root_noise: optional float32 [n,7] mixed into the root priors (AZ mode)."""
         b = self._dev(np.asarray(colour_boards, dtype=np.uint64).reshape(-1, 2), torch.int64)
         n = b.shape[0]
         pl = self._dev(np.asarray(players, dtype=np.int8), torch.int8)
@@ -188,9 +189,13 @@ class Engine:
         action = torch.empty((n,), dtype=torch.int8, device=self.device)
         rootv = torch.empty((n,), dtype=torch.float64, device=self.device)
         stats = RoundStats()
+        noise = None
+        if root_noise is not None:
+            noise = self._dev(np.asarray(root_noise, dtype=np.float32).reshape(n, 7), torch.float32)
         with torch.cuda.device(self.device):
             check(self.lib.nnb_search(self.handle, self._stream(), C.byref(params), n, _ptr(b), _ptr(pl),
-                                      _ptr(visits), _ptr(action), _ptr(rootv), C.byref(stats)), "nnb_search")
+                                      _ptr(noise), _ptr(visits), _ptr(action), _ptr(rootv), C.byref(stats)),
+                  "nnb_search")
         return visits.cpu().numpy(), action.cpu().numpy(), rootv.cpu().numpy(), stats.as_dict()
 
     def selfplay_round(self, n_games: int, params: SearchParams, first_game_id: int = 0,
@@ -210,6 +215,18 @@ class Engine:
                                               first_game_id, _ptr(sb), _ptr(sp), _ptr(traj),
                                               C.byref(stats)), "nnb_selfplay_round")
         return traj, stats.as_dict()
+
+    def dirichlet_noise(self, seed: int, game_ids, move_indices, legal_masks, alpha: float) -> np.ndarray:
+        """The root noise the engine draws for (seed, game id, move index); float32 [n,7]."""
+        gi = self._dev(np.asarray(game_ids, dtype=np.int32), torch.int32)
+        mi = self._dev(np.asarray(move_indices, dtype=np.int32), torch.int32)
+        lg = self._dev(np.asarray(legal_masks, dtype=np.uint8), torch.uint8)
+        n = gi.shape[0]
+        out = torch.empty((n, 7), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.nnb_dirichlet_noise(self._stream(), n, int(seed), _ptr(gi), _ptr(mi), _ptr(lg),
+                                               float(alpha), _ptr(out)), "nnb_dirichlet_noise")
+        return out.cpu().numpy()
 
     # ------------------------------------------------------------------ profiling
     def profile(self, on: bool = True):

@@ -86,6 +86,8 @@ typedef struct nnb_search_params {
     int32_t sims;        /* simulations per move (agent.num_simulations)           */
     int32_t weight_set;  /* which resident weight set NET uses                     */
     int32_t flags;       /* NNB_FLAG_* bits                                        */
+    int32_t rng_move_index; /* nnb_search only: move-index coordinate of the RNG   */
+    int32_t rng_game_base;  /* nnb_search only: root i draws as game rng_game_base+i */
     int32_t reserved;
     double  c_puct;      /* exploration constant (agent.c_puct, default 1.4)       */
     double  dirichlet_alpha;   /* AZ only; 0 disables root noise                   */
@@ -196,11 +198,14 @@ int nnb_net_forward_planes(nnb_engine *engine, int weight_set, void *stream, int
  * action_out [n] = most visited child, lowest column on ties, -1 if the root got no
  * children (the reference returns None, agent_code.py:219-221).
  * root_value_out [n] (may be NULL) = the root's accumulated value sum.
+ * root_noise [n,7] (AZ mode, may be NULL): noise mixed into the root priors with weight
+ * dirichlet_eps; when NULL and dirichlet_alpha > 0 the engine draws Dirichlet(alpha)
+ * noise itself from its counter-based RNG (see nnb_dirichlet_noise).
  * stats_out (host pointer, may be NULL) is filled when the call returns.  Synchronous. */
 int nnb_search(nnb_engine *engine, void *stream, const nnb_search_params *params, int32_t n,
                const uint64_t *root_colour_boards, const int8_t *root_players,
-               int32_t *visits_out, int8_t *action_out, double *root_value_out,
-               nnb_round_stats *stats_out);
+               const float *root_noise, int32_t *visits_out, int8_t *action_out,
+               double *root_value_out, nnb_round_stats *stats_out);
 
 /* Plays n_games <= max_games self-play games to the end in lock step, the same
  * searcher on both sides (self_play, train_alpha_zero.py:33-55).  Game i starts from
@@ -211,6 +216,14 @@ int nnb_selfplay_round(nnb_engine *engine, void *stream, const nnb_search_params
                        int32_t n_games, int32_t first_game_id,
                        const uint64_t *start_colour_boards, const int8_t *start_players,
                        nnb_trajectory *trajectories_out, nnb_round_stats *stats_out);
+
+/* The Dirichlet(alpha) root noise the engine draws for (seed, game id, move index) over the
+ * legal columns of each row: out [n,7], zero on illegal columns, rows sum to 1.  Exposed so a
+ * caller (or a test) can reproduce exactly what an AZ-mode search mixed into its root.
+ * No counterpart in the reference (its search has no noise). */
+int nnb_dirichlet_noise(void *stream, int32_t n, uint64_t seed, const int32_t *game_ids,
+                        const int32_t *move_indices, const uint8_t *legal_masks, double alpha,
+                        float *noise_out);
 
 /* Average device time, in milliseconds, of the `which`-th engine kernel class since
  * the last nnb_profile_reset, measured with HIP events on the launch stream when

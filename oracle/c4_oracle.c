@@ -26,7 +26,9 @@ typedef uint64_t u64;
 #define ORC_ROWS 6
 #define ORC_FULL_MASK 0x0FDFBF7EFDFBFULL /* 6 low bits of each of 7 columns */
 
-enum { ORC_EVAL_CONST = 0, ORC_EVAL_HASH_Q8 = 1, ORC_EVAL_HASH_F32 = 2, ORC_EVAL_CALLBACK = 3 };
+enum { ORC_EVAL_CONST = 0, ORC_EVAL_HASH_Q8 = 1, ORC_EVAL_HASH_F32 = 2, ORC_EVAL_CALLBACK = 3, ORC_EVAL_ROLLOUT = 4 };
+
+int orc_rollout(u64 b1, u64 b2, int mover, u64 seed, uint32_t game_id, uint32_t move_index, uint32_t sim);
 
 /* value callback: (ctx, me_bits, opp_bits) -> value already widened to double */
 typedef double (*orc_eval_fn)(void *ctx, u64 me, u64 opp);
@@ -142,8 +144,9 @@ typedef struct {
  * (mcts.py:35-38); lowest column wins ties (mcts.py:30, agent_code.py:223).
  * Returns the selected column, or -1 when the root never got children.
  */
-int orc_compat_search(u64 b1, u64 b2, int player, int sims, double c_puct, int eval_kind,
-                      orc_eval_fn fn, void *ctx, int32_t *visits_out, orc_stats *st) {
+static int compat_search_impl(u64 b1, u64 b2, int player, int sims, double c_puct, int eval_kind,
+                              orc_eval_fn fn, void *ctx, u64 seed, uint32_t game_id, uint32_t move_index,
+                              int32_t *visits_out, orc_stats *st) {
     int cap = 1 + 7 * sims;
     int32_t *visits = (int32_t *)calloc(cap, sizeof(int32_t));
     double *value = (double *)calloc(cap, sizeof(double));
@@ -178,7 +181,14 @@ int orc_compat_search(u64 b1, u64 b2, int player, int sims, double c_puct, int e
         } else {
             int legal = orc_legal_mask(c1, c2);
             u64 me = player == 1 ? c1 : c2, opp = player == 1 ? c2 : c1;
-            reward = eval_leaf(eval_kind, fn, ctx, me, opp);
+            if (eval_kind == ORC_EVAL_ROLLOUT) {
+                /* no counterpart in the reference: a uniformly random playout whose value is the
+                   final position's get_reward() (absolute frame), the root mover moving first */
+                int res = orc_rollout(c1, c2, player, seed, game_id, move_index, (uint32_t)s);
+                reward = res == 1 ? -1.0 : (res == -1 ? 1.0 : 0.0);
+            } else {
+                reward = eval_leaf(eval_kind, fn, ctx, me, opp);
+            }
             ++evals;
             first[node] = n_nodes;
             for (int c = 0; c < ORC_COLS; ++c) {
@@ -203,6 +213,18 @@ int orc_compat_search(u64 b1, u64 b2, int player, int sims, double c_puct, int e
     }
     free(visits); free(value); free(parent); free(first); free(nchild); free(action);
     return best_a;
+}
+
+int orc_compat_search(u64 b1, u64 b2, int player, int sims, double c_puct, int eval_kind,
+                      orc_eval_fn fn, void *ctx, int32_t *visits_out, orc_stats *st) {
+    return compat_search_impl(b1, b2, player, sims, c_puct, eval_kind, fn, ctx, 0, 0, 0, visits_out, st);
+}
+
+/* same search with the rollout evaluator's RNG coordinates (seed, game, move index) */
+int orc_compat_search_seeded(u64 b1, u64 b2, int player, int sims, double c_puct, int eval_kind, u64 seed,
+                             uint32_t game_id, uint32_t move_index, int32_t *visits_out, orc_stats *st) {
+    return compat_search_impl(b1, b2, player, sims, c_puct, eval_kind, NULL, NULL, seed, game_id, move_index,
+                              visits_out, st);
 }
 
 /*
@@ -232,3 +254,159 @@ int orc_selfplay_game(u64 b1, u64 b2, int player, int sims, double c_puct, int e
     if (total) *total = acc;
     return ply;
 }
+
+/* =======================================================================
+ * PUCT search ("AZ" mode) and the random-rollout evaluator.
+ *
+ * The reference has neither (its search ignores priors, mcts.py:35-38, and has
+ * no rollouts), so nothing below is pinned by the reference: PARITY UNPINNED.
+ * This is the specification the device kernels are held to, bit for bit:
+ *   - node statistics N (visits) and W (value sum seen by the player who moved
+ *     INTO the node); children contiguous, ascending column;
+ *   - selection at a node with N_p visits: argmax over children of
+ *        Q + U,  Q = N>0 ? W/N : 0,  U = c_puct * P * sqrt(N_p) / (1 + N)
+ *     in float64 in exactly this operation order, lowest column on ties;
+ *   - descent alternates colours; a leaf is evaluated from the side to move
+ *     (value v in [-1,1], priors over legal columns); a terminal leaf has
+ *     v = -1 if the previous mover completed four, else 0;
+ *   - backup: leaf gets W += -v, its parent W += +v, alternating to the root,
+ *     every node on the path N += 1;
+ *   - root priors are mixed with caller-supplied noise when the root is
+ *     expanded: P = (float)((1-eps)*P + eps*noise);
+ *   - move = most visited root child, lowest column on ties.
+ * ===================================================================== */
+
+typedef void (*orc_az_eval_fn)(void *ctx, u64 me, u64 opp, int legal, float *priors7, float *value);
+
+void orc_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                    uint32_t out[4]) {
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* Uniformly random playout from (b1,b2) with `mover` to move, one Philox word per ply:
+ * counter = (game_id, move_index, sim, rollout_ply/4), key = seed.  Returns orc_result(). */
+int orc_rollout(u64 b1, u64 b2, int mover, u64 seed, uint32_t game_id, uint32_t move_index, uint32_t sim) {
+    uint32_t rnd[4];
+    for (int rp = 0; rp < 42; ++rp) {
+        if (orc_is_terminal(b1, b2)) break;
+        int legal = orc_legal_mask(b1, b2);
+        if (!legal) break;
+        if ((rp & 3) == 0)
+            orc_philox4x32(game_id, move_index, sim, (uint32_t)(rp >> 2), (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+        int nl = __builtin_popcount(legal);
+        int idx = (int)(((uint64_t)rnd[rp & 3] * (uint64_t)nl) >> 32);
+        int m = legal;
+        for (int k = 0; k < idx; ++k) m &= m - 1;
+        orc_drop(&b1, &b2, mover, __builtin_ctz(m));
+        mover = 3 - mover;
+    }
+    return orc_result(b1, b2);
+}
+
+/* priors of the fixed evaluators: uniform, or weights 1 + byte_a of the position hash */
+void orc_fixed_priors(int kind, u64 me, u64 opp, int legal, float *p) {
+    int nl = __builtin_popcount(legal);
+    if (kind == ORC_EVAL_HASH_Q8 || kind == ORC_EVAL_HASH_F32) {
+        u64 h = orc_mix64(me, opp);
+        float sum = 0.0f;
+        for (int a = 0; a < 7; ++a) {
+            p[a] = ((legal >> a) & 1) ? (float)(1 + (int)((h >> (8 * a)) & 0xFF)) : 0.0f;
+            sum += p[a];
+        }
+        for (int a = 0; a < 7; ++a) p[a] = p[a] / sum;
+    } else {
+        for (int a = 0; a < 7; ++a) p[a] = ((legal >> a) & 1) ? (float)(1.0 / (double)nl) : 0.0f;
+    }
+}
+
+int orc_az_search(u64 b1, u64 b2, int player, int sims, double c_puct, int eval_kind, orc_az_eval_fn fn,
+                  void *ctx, const float *root_noise, double eps, u64 seed, uint32_t game_id,
+                  uint32_t move_index, int32_t *visits_out, orc_stats *st) {
+    int cap = 1 + 7 * sims;
+    int32_t *visits = (int32_t *)calloc(cap, sizeof(int32_t));
+    double *value = (double *)calloc(cap, sizeof(double));
+    float *prior = (float *)calloc(cap, sizeof(float));
+    int32_t *parent = (int32_t *)malloc(cap * sizeof(int32_t));
+    int32_t *first = (int32_t *)malloc(cap * sizeof(int32_t));
+    int8_t *nchild = (int8_t *)calloc(cap, 1);
+    int8_t *action = (int8_t *)malloc(cap);
+    int n_nodes = 1;
+    int64_t depth_sum = 0, evals = 0, term = 0;
+    parent[0] = -1; first[0] = -1; action[0] = -1;
+
+    for (int s = 0; s < sims; ++s) {
+        int node = 0, mover = player, depth = 0;
+        u64 c1 = b1, c2 = b2;
+        while (nchild[node] > 0 && !orc_is_terminal(c1, c2)) {
+            double sq = sqrt((double)visits[node]);
+            double best_score = -INFINITY;
+            int best = -1;
+            for (int ch = first[node]; ch < first[node] + nchild[node]; ++ch) {
+                double n = (double)visits[ch];
+                double q = visits[ch] > 0 ? value[ch] / n : 0.0;
+                double u = c_puct * (double)prior[ch] * sq / (1.0 + n);
+                double score = q + u;
+                if (score > best_score) { best_score = score; best = ch; }
+            }
+            node = best;
+            orc_drop(&c1, &c2, mover, action[node]);
+            mover = 3 - mover;
+            ++depth;
+        }
+        depth_sum += depth;
+        double v;                                   /* value for the side to move at the leaf */
+        int legal = orc_legal_mask(c1, c2);
+        if (orc_is_terminal(c1, c2) || !legal) {
+            v = (orc_has_four(c1) || orc_has_four(c2)) ? -1.0 : 0.0;
+            ++term;
+        } else {
+            u64 me = mover == 1 ? c1 : c2, opp = mover == 1 ? c2 : c1;
+            float p[7], fv = 0.0f;
+            if (eval_kind == ORC_EVAL_CALLBACK) {
+                fn(ctx, me, opp, legal, p, &fv);
+                v = (double)fv;
+            } else if (eval_kind == ORC_EVAL_ROLLOUT) {
+                orc_fixed_priors(ORC_EVAL_CONST, me, opp, legal, p);
+                int res = orc_rollout(c1, c2, mover, seed, game_id, move_index, (uint32_t)s);
+                v = (res == 2 || res == 0) ? 0.0 : ((res == 1) == (mover == 1) ? 1.0 : -1.0);
+            } else {
+                orc_fixed_priors(eval_kind, me, opp, legal, p);
+                v = eval_leaf(eval_kind, NULL, NULL, me, opp);
+            }
+            ++evals;
+            first[node] = n_nodes;
+            for (int c = 0; c < ORC_COLS; ++c) {
+                if (!((legal >> c) & 1)) continue;
+                float pc = p[c];
+                if (node == 0 && root_noise)
+                    pc = (float)((1.0 - eps) * (double)pc + eps * (double)root_noise[c]);
+                visits[n_nodes] = 0; value[n_nodes] = 0.0; prior[n_nodes] = pc; parent[n_nodes] = node;
+                first[n_nodes] = -1; nchild[n_nodes] = 0; action[n_nodes] = (int8_t)c;
+                ++n_nodes; ++nchild[node];
+            }
+        }
+        double sign = -1.0;
+        for (int n = node; n >= 0; n = parent[n]) { visits[n] += 1; value[n] += sign * v; sign = -sign; }
+    }
+
+    int best_a = -1, best_v = -1;
+    for (int c = 0; c < ORC_COLS; ++c) visits_out[c] = 0;
+    for (int ch = first[0]; nchild[0] > 0 && ch < first[0] + nchild[0]; ++ch) {
+        visits_out[action[ch]] = visits[ch];
+        if (visits[ch] > best_v) { best_v = visits[ch]; best_a = action[ch]; }
+    }
+    if (st) {
+        st->nodes = n_nodes; st->depth_sum = depth_sum; st->evals = evals; st->terminal_hits = term;
+        st->root_visits = visits[0]; st->root_value = value[0];
+    }
+    free(visits); free(value); free(prior); free(parent); free(first); free(nchild); free(action);
+    return best_a;
+}
+

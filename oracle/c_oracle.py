@@ -14,10 +14,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle.so")
 
-EVAL_CONST, EVAL_HASH_Q8, EVAL_HASH_F32, EVAL_CALLBACK = 0, 1, 2, 3
-EVAL_KINDS = {"const": EVAL_CONST, "hash_q8": EVAL_HASH_Q8, "hash_f32": EVAL_HASH_F32}
+EVAL_CONST, EVAL_HASH_Q8, EVAL_HASH_F32, EVAL_CALLBACK, EVAL_ROLLOUT = 0, 1, 2, 3, 4
+EVAL_KINDS = {"const": EVAL_CONST, "hash_q8": EVAL_HASH_Q8, "hash_f32": EVAL_HASH_F32,
+              "rollout": EVAL_ROLLOUT}
 
 EVAL_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_uint64, C.c_uint64)
+AZ_EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_float),
+                         C.POINTER(C.c_float))
 
 
 class Stats(C.Structure):
@@ -63,6 +66,14 @@ def lib():
                                         C.c_void_p, C.c_int, C.POINTER(C.c_int8),
                                         C.POINTER(C.c_int32), C.POINTER(C.c_int), C.POINTER(u64),
                                         C.POINTER(Stats)]
+        L.orc_compat_search_seeded.argtypes = [u64, u64, C.c_int, C.c_int, C.c_double, C.c_int, u64, C.c_uint32,
+                                               C.c_uint32, C.POINTER(C.c_int32), C.POINTER(Stats)]
+        L.orc_az_search.argtypes = [u64, u64, C.c_int, C.c_int, C.c_double, C.c_int, AZ_EVAL_FN, C.c_void_p,
+                                    C.POINTER(C.c_float), C.c_double, u64, C.c_uint32, C.c_uint32,
+                                    C.POINTER(C.c_int32), C.POINTER(Stats)]
+        L.orc_rollout.argtypes = [u64, u64, C.c_int, u64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_philox4x32.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
+        L.orc_fixed_priors.argtypes = [C.c_int, u64, u64, C.c_int, C.POINTER(C.c_float)]
         _lib = L
     return _lib
 
@@ -108,3 +119,37 @@ def selfplay_game(sims, c_puct, evaluator, b1=0, b2=0, player=1, max_plies=42):
     v = np.array(visits, dtype=np.int32).reshape(42, 7)[:n]
     res = None if result.value == 2 else result.value
     return [int(m) for m in moves[:n]], v.tolist(), res, (final[0], final[1]), st
+
+
+def compat_search_seeded(b1, b2, player, sims, c_puct, evaluator, seed=0, game_id=0, move_index=0):
+    """compat search whose rollout evaluator draws at RNG coordinates (seed, game_id, move_index)."""
+    visits = (C.c_int32 * 7)()
+    st = Stats()
+    a = lib().orc_compat_search_seeded(b1, b2, player, sims, c_puct, EVAL_KINDS[evaluator], seed, game_id,
+                                       move_index, visits, C.byref(st))
+    return (None if a < 0 else a), list(visits), st
+
+
+_NULL_AZ_FN = AZ_EVAL_FN(0)
+
+
+def az_search(b1, b2, player, sims, c_puct, evaluator, root_noise=None, eps=0.0, seed=0, game_id=0,
+              move_index=0):
+    """PUCT search.  evaluator: a name from EVAL_KINDS, or callable(me, opp, legal) -> (priors[7], value)."""
+    visits = (C.c_int32 * 7)()
+    st = Stats()
+    noise = None
+    if root_noise is not None:
+        noise = (C.c_float * 7)(*[float(x) for x in root_noise])
+    if isinstance(evaluator, str):
+        kind, fn = EVAL_KINDS[evaluator], _NULL_AZ_FN
+    else:
+        def _cb(ctx, me, opp, legal, pri, val):
+            p, v = evaluator(me, opp, legal)
+            for i in range(7):
+                pri[i] = float(p[i])
+            val[0] = float(v)
+        kind, fn = EVAL_CALLBACK, AZ_EVAL_FN(_cb)
+    a = lib().orc_az_search(b1, b2, player, sims, c_puct, kind, fn, None, noise, eps, seed, game_id, move_index,
+                            visits, C.byref(st))
+    return (None if a < 0 else a), list(visits), st
