@@ -16,12 +16,14 @@ EVAL_NET, EVAL_CONST, EVAL_HASH_Q8, EVAL_HASH_F32, EVAL_ROLLOUT = 0, 1, 2, 3, 4
 EVALUATORS = {"net": EVAL_NET, "const": EVAL_CONST, "hash_q8": EVAL_HASH_Q8,
               "hash_f32": EVAL_HASH_F32, "rollout": EVAL_ROLLOUT}
 FLAG_LOCKSTEP = 1
+NET_F16, NET_F32 = 0, 1
+PRECISIONS = {"f16": NET_F16, "f32": NET_F32}
 MODES = {"compat": MODE_COMPAT, "az": MODE_AZ}
 
 
 class Config(C.Structure):
     _fields_ = [("max_games", C.c_int32), ("max_sims", C.c_int32), ("device", C.c_int32),
-                ("n_weight_sets", C.c_int32)]
+                ("n_weight_sets", C.c_int32), ("net_precision", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SearchParams(C.Structure):

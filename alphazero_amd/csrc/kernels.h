@@ -34,12 +34,16 @@ struct NetWeights {            // one resident weight set, kernel layouts
     float *conv4_w, *conv4_b;
     float *fc_w, *fc_b;        // repacked [1440][2][1024][4], [1024]
     float *heads_w, *heads_b;  // [8][1024], [8]
+    // half-precision-input path (net_kernels_f16.hip); null when the engine runs the f32 path
+    void *conv2_wh, *conv4_wh; // half [16][8][2][128][8]
+    void *fc_wh;               // half [720][2][1024][8]
 };
 struct NetBuffers {            // activations, channels-last float32
     float *act1;               // [G][7][8][128]
     float *act2;               // [G][8][9][128]
     float *act3;               // [G][9][10][128]
     float *fc;                 // [G][1024]
+    float *fcpart;             // [2][G][1024] split-K partial sums (f16 path)
     int max_rows;              // G
 };
 enum NetStage { NET_CONV0 = 0, NET_CONV2 = 1, NET_CONV4 = 2, NET_FC = 3, NET_HEADS = 4 };
@@ -55,5 +59,13 @@ void launch_planes_to_bits(hipStream_t st, int n, const float *planes, u64 *side
 void launch_net_stage(hipStream_t st, int stage, const NetWeights &w, const NetBuffers &b, const u64 *side,
                       const uint8_t *legal, float *logp_out, float *value_out, float *prior_out,
                       const int32_t *count_ptr, int n_max);
+
+// net_kernels_f16.hip: same stages with half activations / weights on v_mfma_f32_32x32x16_f16
+hipError_t prepare_net_kernels_f16();
+void launch_repack_f16(hipStream_t st, const NetWeights &dst, const float *conv2_w, const float *conv4_w,
+                       const float *fc_w);
+void launch_net_stage_f16(hipStream_t st, int stage, const NetWeights &w, const NetBuffers &b, const u64 *side,
+                          const uint8_t *legal, float *logp_out, float *value_out, float *prior_out,
+                          const int32_t *count_ptr, int n_max);
 
 }  // namespace nnb

@@ -408,11 +408,11 @@ void launch_repack(hipStream_t st, const NetWeights &dst, const float *conv0_w, 
                    const float *value_w, const float *value_b) {
     copy_kernel<<<cdiv(128 * 32, 256), 256, 0, st>>>(conv0_w, dst.conv0_w, 128 * 32);
     copy_kernel<<<1, 256, 0, st>>>(conv0_b, dst.conv0_b, 128);
-    repack_conv_kernel<<<cdiv(128 * 128 * 16, 256), 256, 0, st>>>(conv2_w, dst.conv2_w);
+    if (dst.conv2_w) repack_conv_kernel<<<cdiv(128 * 128 * 16, 256), 256, 0, st>>>(conv2_w, dst.conv2_w);
     copy_kernel<<<1, 256, 0, st>>>(conv2_b, dst.conv2_b, 128);
-    repack_conv_kernel<<<cdiv(128 * 128 * 16, 256), 256, 0, st>>>(conv4_w, dst.conv4_w);
+    if (dst.conv4_w) repack_conv_kernel<<<cdiv(128 * 128 * 16, 256), 256, 0, st>>>(conv4_w, dst.conv4_w);
     copy_kernel<<<1, 256, 0, st>>>(conv4_b, dst.conv4_b, 128);
-    repack_fc_kernel<<<(1024 * 11520) / 256, 256, 0, st>>>(fc_w, dst.fc_w);
+    if (dst.fc_w) repack_fc_kernel<<<(1024 * 11520) / 256, 256, 0, st>>>(fc_w, dst.fc_w);
     copy_kernel<<<4, 256, 0, st>>>(fc_b, dst.fc_b, 1024);
     repack_heads_kernel<<<32, 256, 0, st>>>(policy_w, policy_b, value_w, value_b, dst.heads_w, dst.heads_b);
 }

@@ -1,0 +1,428 @@
+// Half-precision-input variant of the policy-value network kernels (gfx950).
+//
+// Same layer structure as net_kernels.hip (Connect4Net.forward,
+// nnbattle/agents/alphazero/network.py:43-50), but activations and the repacked
+// conv / linear weights are stored as IEEE half and multiplied on
+// v_mfma_f32_32x32x16_f16 with float32 accumulation (16x the f32 matrix rate).  Bias,
+// ReLU, the heads, log-softmax and tanh stay in float32.  On the seed-0 random-init
+// network the outputs differ from the float32 CPU forward by about 1e-5 absolute.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "c4_bits.h"
+#include "engine_layout.h"
+#include "kernels.h"
+
+namespace nnb {
+
+using c4::u64;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ int batch_count16(const int32_t *count_ptr, int n_fixed) {
+    return count_ptr ? *count_ptr : n_fixed;
+}
+
+__device__ __forceinline__ half8 as_half8(uint4 v) {
+    union { uint4 u; half8 h; } x;
+    x.u = v;
+    return x.h;
+}
+
+// ---------------------------------------------------------------------------
+// Weight repacking.  One MFMA consumes 16 input channels: lane (n, h) holds channels
+// 16*ks + 8*h + {0..7} of output channel n, i.e. one 16-byte load.
+// ---------------------------------------------------------------------------
+// Conv2d weight f32 [n=128][c=128][kh][kw] -> half [tap][ks=c/16][h=(c%16)/8][n][c%8]
+__global__ void repack_conv_f16_kernel(const float *__restrict__ w, _Float16 *__restrict__ wp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 128 * 128 * 16) return;
+    int j = i & 7, n = (i >> 3) & 127, h = (i >> 10) & 1, ks = (i >> 11) & 7, tap = i >> 14;
+    int c = ks * 16 + h * 8 + j, kh = tap >> 2, kw = tap & 3;
+    wp[i] = (_Float16)w[((n * 128 + c) * 4 + kh) * 4 + kw];
+}
+
+// Linear weight f32 [n=1024][c*90 + hw] -> half [ks=kk/16][h][n][kk%8], kk = hw*128 + c
+__global__ void repack_fc_f16_kernel(const float *__restrict__ w, _Float16 *__restrict__ wp) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)1024 * 11520) return;
+    int j = i & 7, n = (i >> 3) & 1023, h = (i >> 13) & 1;
+    int ks = (int)(i >> 14);
+    int kk = ks * 16 + h * 8 + j, hw = kk >> 7, c = kk & 127;
+    wp[i] = (_Float16)w[(size_t)n * 11520 + c * 90 + hw];
+}
+
+// ---------------------------------------------------------------------------
+// Leaf encode fused with conv 2->128 (network.py:29-30), half output
+// [board][7][8][128].  The sums are formed in float32 exactly as in the f32 path.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void conv_in_f16_kernel(const u64 *__restrict__ side, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, _Float16 *__restrict__ out,
+                                                          const int32_t *__restrict__ count_ptr, int n_fixed) {
+    const int count = batch_count16(count_ptr, n_fixed);
+    const int n = threadIdx.x;
+    float wr[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) wr[k] = w[n * 32 + k];
+    const float b = bias[n];
+    for (int board = blockIdx.x; board < count; board += gridDim.x) {
+        unsigned lo0 = __builtin_amdgcn_readfirstlane((unsigned)side[2 * board]);
+        unsigned hi0 = __builtin_amdgcn_readfirstlane((unsigned)(side[2 * board] >> 32));
+        unsigned lo1 = __builtin_amdgcn_readfirstlane((unsigned)side[2 * board + 1]);
+        unsigned hi1 = __builtin_amdgcn_readfirstlane((unsigned)(side[2 * board + 1] >> 32));
+        const u64 pl[2] = {((u64)hi0 << 32) | lo0, ((u64)hi1 << 32) | lo1};
+        _Float16 *o = out + (size_t)board * 56 * 128 + n;
+#pragma unroll
+        for (int oh = 0; oh < 7; ++oh) {
+#pragma unroll
+            for (int ow = 0; ow < 8; ++ow) {
+                float acc = b;
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                    for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 4; ++kw) {
+                            const int ih = oh + kh - 2, iw = ow + kw - 2;
+                            if (ih >= 0 && ih < 6 && iw >= 0 && iw < 7) {
+                                if ((pl[ci] >> (iw * 7 + (5 - ih))) & 1) acc += wr[(ci * 4 + kh) * 4 + kw];
+                            }
+                        }
+                o[(oh * 8 + ow) * 128] = (_Float16)fmaxf(acc, 0.0f);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// conv 128->128, 4x4, pad 2, + bias + ReLU (network.py:31-34): implicit GEMM on
+// v_mfma_f32_32x32x16_f16.  in/out: half, channels-last.
+// Block = NB boards staged once in LDS (256-byte rows of 16 chunks, chunk q of row p
+// stored at q ^ (p & 15); one extra all-zero row for out-of-range taps).  Wave w owns
+// output channels 32w..32w+31 for all MT row tiles; weights stream L2 -> VGPR.
+// ---------------------------------------------------------------------------
+template <int IH, int IW, int NB, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv_mid_f16_kernel(const _Float16 *__restrict__ in,
+                                                                           const _Float16 *__restrict__ wp,
+                                                                           const float *__restrict__ bias,
+                                                                           _Float16 *__restrict__ out,
+                                                                           const int32_t *__restrict__ count_ptr,
+                                                                           int n_fixed) {
+    constexpr int OH = IH + 1, OW = IW + 1, IP = IH * IW, OP = OH * OW;
+    constexpr int M = NB * OP, MT = (M + 31) / 32, ROWS = NB * IP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);          // [(ROWS+1)][16] x 16 bytes
+
+    const int count = batch_count16(count_ptr, n_fixed);
+    const int b0 = blockIdx.x * NB;
+    if (b0 >= count) return;
+    const int nb_valid = min(NB, count - b0);
+    const int tid = threadIdx.x;
+
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    const uint4 *src = reinterpret_cast<const uint4 *>(in + (size_t)b0 * IP * 128);
+    for (int e = tid; e < ROWS * 16; e += 256) {
+        int p = e >> 4, q = e & 15;
+        uint4 v = (p < nb_valid * IP) ? src[e] : zero4;
+        lds[p * 16 + (q ^ (p & 15))] = v;
+    }
+    if (tid < 16) lds[ROWS * 16 + tid] = zero4;
+    __syncthreads();
+
+    const int lane = tid & 63, w = tid >> 6, m = lane & 31, h = lane >> 5;
+    int pbase[MT], ohv[MT], owv[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        int r = t * 32 + m;
+        int j = r / OP, o = r % OP;
+        ohv[t] = (r < M) ? o / OW : -100;
+        owv[t] = o % OW;
+        pbase[t] = j * IP + (o / OW) * IW + (o % OW);
+    }
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const uint4 *wlane = reinterpret_cast<const uint4 *>(wp) + h * 128 + w * 32 + m;
+    uint4 bnext = wlane[0];
+    for (int tap = 0; tap < 16; ++tap) {
+        const int dh = (tap >> 2) - 2, dw = (tap & 3) - 2;
+        int rowoff[MT], sw[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            int ih = ohv[t] + dh, iw = owv[t] + dw;
+            bool ok = (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
+            int p = ok ? pbase[t] + dh * IW + dw : ROWS;
+            rowoff[t] = p * 16;
+            sw[t] = p & 15;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const half8 b = as_half8(bnext);
+            int nxt = tap * 8 + ks + 1;
+            nxt = nxt < 128 ? nxt : 127;
+            bnext = wlane[nxt * 256];
+            const int q = 2 * ks + h;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const half8 a = as_half8(lds[rowoff[t] + (q ^ sw[t])]);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    const float bv = bias[w * 32 + m];
+    _Float16 *obase = out + (size_t)b0 * OP * 128 + w * 32 + m;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int R = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (R < M && R < nb_valid * OP) obase[(size_t)R * 128] = (_Float16)fmaxf(acc[t][r] + bv, 0.f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// linear 11520->1024 (network.py:36-39,46-47) on v_mfma_f32_32x32x16_f16, split in two
+// halves of K.  Block tile 128 rows x 256 columns, 4 waves; wave w owns columns
+// 64w..64w+63 (two 32-column tiles) for all four 32-row tiles, so each A fragment read
+// from LDS feeds two MFMAs.  Raw float32 partial sums go to part[ksplit][row][1024];
+// the heads kernel adds the halves, the bias and the ReLU.
+// Block order: the 32 blocks that share blockIdx % 8 (observed to share an XCD and its L2)
+// cover 4 row blocks x (4 column blocks x 2 K halves), so each A slab is fetched into that
+// L2 once and re-read by 8 blocks.
+// ---------------------------------------------------------------------------
+constexpr int FCH_K = 11520, FCH_N = 1024, FCH_BM = 128, FCH_BN = 256, FCH_BK = 64, FCH_SPLIT = 2;
+
+__global__ __launch_bounds__(256, 1) void fc_f16_kernel(const _Float16 *__restrict__ a,   // [rows][11520]
+                                                        const _Float16 *__restrict__ wp,  // repacked
+                                                        float *__restrict__ part,         // [2][max_rows][1024]
+                                                        const int32_t *__restrict__ count_ptr, int n_fixed,
+                                                        int max_rows) {
+    __shared__ __attribute__((aligned(16))) uint4 lds[2][FCH_BM * 8];      // 128 rows x 64 halfs, two buffers
+    const int count = batch_count16(count_ptr, n_fixed);
+    const int bid = blockIdx.x;
+    const int x = bid & 7, i = bid >> 3;                    // i in [0, 32 * groups)
+    const int grp = i >> 5, ii = i & 31;
+    const int mb = (grp * 8 + x) * 4 + (ii & 3);
+    const int nb = (ii >> 2) & 3, ksp = ii >> 4;
+    const int row0 = mb * FCH_BM;
+    if (row0 >= count) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, m = lane & 31, h = lane >> 5;
+
+    constexpr int KHALF = FCH_K / FCH_SPLIT;                // 5760
+    constexpr int NSLAB = KHALF / FCH_BK;                   // 90
+    const int k0 = ksp * KHALF;
+
+    // staging map: 128 rows x 8 chunks of 16 bytes = 1024 chunks, 4 per thread
+    int srow[4], scol[4];
+    const uint4 *abase[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        int e = tid + 256 * s;
+        srow[s] = e >> 3; scol[s] = e & 7;
+        int r = min(row0 + srow[s], max_rows - 1);
+        abase[s] = reinterpret_cast<const uint4 *>(a + (size_t)r * FCH_K + k0) + scol[s];
+    }
+    uint4 stage[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) stage[s] = abase[s][0];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) lds[0][srow[s] * 8 + (scol[s] ^ ((srow[s] >> 1) & 7))] = stage[s];
+    __syncthreads();
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    // weight fragment of (k-step, column tile): ((kstep*2 + h)*1024 + n) * 16 bytes
+    const uint4 *wlane = reinterpret_cast<const uint4 *>(wp) + (size_t)(k0 / 16) * 2 * FCH_N + h * FCH_N +
+                         nb * FCH_BN + w * 64 + m;
+    uint4 bn0 = wlane[0], bn1 = wlane[32];
+    for (int s = 0; s < NSLAB; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < NSLAB) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) stage[c] = abase[c][(s + 1) * 8];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const half8 b0 = as_half8(bn0), b1 = as_half8(bn1);
+            int nxt = s * 4 + ks + 1;
+            nxt = nxt < NSLAB * 4 ? nxt : NSLAB * 4 - 1;
+            bn0 = wlane[(size_t)nxt * 2 * FCH_N];
+            bn1 = wlane[(size_t)nxt * 2 * FCH_N + 32];
+            const int q = 2 * ks + h;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = t * 32 + m;
+                const half8 av = as_half8(lds[cur][row * 8 + (q ^ ((row >> 1) & 7))]);
+                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[t][1], 0, 0, 0);
+            }
+        }
+        if (s + 1 < NSLAB) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lds[cur ^ 1][srow[c] * 8 + (scol[c] ^ ((srow[c] >> 1) & 7))] = stage[c];
+        }
+        __syncthreads();
+    }
+
+    float *obase = part + (size_t)ksp * max_rows * FCH_N + nb * FCH_BN + w * 64 + m;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = row0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < count) {
+                obase[(size_t)row * FCH_N] = acc[t][0][r];
+                obase[(size_t)row * FCH_N + 32] = acc[t][1][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Heads over split linear-layer partial sums: x = ReLU(part[0] + part[1] + bias), then
+// 1024->7 log-softmax, 1024->1 tanh and the legal-move mask (network.py:40-41,48-49,
+// agent_code.py:199-208).  One wave per row.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void heads_split_kernel(const float *__restrict__ part, int max_rows,
+                                                          const float *__restrict__ fc_bias,
+                                                          const float *__restrict__ hw, const float *__restrict__ hb,
+                                                          const uint8_t *__restrict__ legal,
+                                                          float *__restrict__ logp_out, float *__restrict__ value_out,
+                                                          float *__restrict__ prior_out,
+                                                          const int32_t *__restrict__ count_ptr, int n_fixed) {
+    const int count = batch_count16(count_ptr, n_fixed);
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int row = wave; row < count; row += nwaves) {
+        const float4 *p0 = reinterpret_cast<const float4 *>(part + (size_t)row * 1024);
+        const float4 *p1 = reinterpret_cast<const float4 *>(part + ((size_t)max_rows + row) * 1024);
+        const float4 *fb = reinterpret_cast<const float4 *>(fc_bias);
+        float4 xv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 u = p0[lane + 64 * i], v = p1[lane + 64 * i], bb = fb[lane + 64 * i];
+            xv[i].x = fmaxf(u.x + v.x + bb.x, 0.f);
+            xv[i].y = fmaxf(u.y + v.y + bb.y, 0.f);
+            xv[i].z = fmaxf(u.z + v.z + bb.z, 0.f);
+            xv[i].w = fmaxf(u.w + v.w + bb.w, 0.f);
+        }
+        float z[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const float4 *wr = reinterpret_cast<const float4 *>(hw + o * 1024);
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 wv = wr[lane + 64 * i];
+                s += xv[i].x * wv.x + xv[i].y * wv.y + xv[i].z * wv.z + xv[i].w * wv.w;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+            z[o] = s + hb[o];
+        }
+        if (lane == 0) {
+            float mx = z[0];
+#pragma unroll
+            for (int o = 1; o < 7; ++o) mx = fmaxf(mx, z[o]);
+            float sum = 0.f;
+#pragma unroll
+            for (int o = 0; o < 7; ++o) sum += expf(z[o] - mx);
+            const float lse = mx + logf(sum);
+            float lp[7];
+#pragma unroll
+            for (int o = 0; o < 7; ++o) lp[o] = z[o] - lse;
+            if (logp_out)
+#pragma unroll
+                for (int o = 0; o < 7; ++o) logp_out[(size_t)row * 7 + o] = lp[o];
+            if (value_out) value_out[row] = tanhf(z[7]);
+            if (prior_out && legal) {
+                const unsigned mask = legal[row];
+                double f[7], tot = 0.0;
+#pragma unroll
+                for (int o = 0; o < 7; ++o) {
+                    f[o] = ((mask >> o) & 1) ? (double)expf(lp[o]) : 0.0;
+                    tot += f[o];
+                }
+                const int nl = __popc(mask);
+#pragma unroll
+                for (int o = 0; o < 7; ++o) {
+                    double pr = tot > 0.0 ? f[o] / tot : (((mask >> o) & 1) ? 1.0 / nl : 0.0);
+                    prior_out[(size_t)row * 7 + o] = (float)pr;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Host launchers
+// ---------------------------------------------------------------------------
+static inline int cdiv16(int a, int b) { return (a + b - 1) / b; }
+
+constexpr int C2H_NB = 4, C4H_NB = 2;
+constexpr size_t C2H_LDS = (size_t)(C2H_NB * 7 * 8 + 1) * 256;
+constexpr size_t C4H_LDS = (size_t)(C4H_NB * 8 * 9 + 1) * 256;
+
+hipError_t prepare_net_kernels_f16() {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mid_f16_kernel<7, 8, C2H_NB, 2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)C2H_LDS);
+    if (err != hipSuccess) return err;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mid_f16_kernel<8, 9, C4H_NB, 2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C4H_LDS);
+}
+
+void launch_repack_f16(hipStream_t st, const NetWeights &dst, const float *conv2_w, const float *conv4_w,
+                       const float *fc_w) {
+    repack_conv_f16_kernel<<<cdiv16(128 * 128 * 16, 256), 256, 0, st>>>(conv2_w, (_Float16 *)dst.conv2_wh);
+    repack_conv_f16_kernel<<<cdiv16(128 * 128 * 16, 256), 256, 0, st>>>(conv4_w, (_Float16 *)dst.conv4_wh);
+    repack_fc_f16_kernel<<<(1024 * 11520) / 256, 256, 0, st>>>(fc_w, (_Float16 *)dst.fc_wh);
+}
+
+void launch_net_stage_f16(hipStream_t st, int stage, const NetWeights &w, const NetBuffers &b, const u64 *side,
+                          const uint8_t *legal, float *logp_out, float *value_out, float *prior_out,
+                          const int32_t *count_ptr, int n_max) {
+    if (n_max <= 0) return;
+    _Float16 *a1 = reinterpret_cast<_Float16 *>(b.act1), *a2 = reinterpret_cast<_Float16 *>(b.act2),
+             *a3 = reinterpret_cast<_Float16 *>(b.act3);
+    switch (stage) {
+    case NET_CONV0:
+        conv_in_f16_kernel<<<n_max < 2048 ? n_max : 2048, 128, 0, st>>>(side, w.conv0_w, w.conv0_b, a1, count_ptr,
+                                                                         n_max);
+        break;
+    case NET_CONV2:
+        conv_mid_f16_kernel<7, 8, C2H_NB, 2><<<cdiv16(n_max, C2H_NB), 256, C2H_LDS, st>>>(
+            a1, (const _Float16 *)w.conv2_wh, w.conv2_b, a2, count_ptr, n_max);
+        break;
+    case NET_CONV4:
+        conv_mid_f16_kernel<8, 9, C4H_NB, 2><<<cdiv16(n_max, C4H_NB), 256, C4H_LDS, st>>>(
+            a2, (const _Float16 *)w.conv4_wh, w.conv4_b, a3, count_ptr, n_max);
+        break;
+    case NET_FC: {
+        int groups = cdiv16(cdiv16(n_max, FCH_BM), 32);      // 32 row blocks per group of 256 blocks
+        fc_f16_kernel<<<256 * groups, 256, 0, st>>>(a3, (const _Float16 *)w.fc_wh, b.fcpart, count_ptr, n_max,
+                                                    b.max_rows);
+        break;
+    }
+    case NET_HEADS: {
+        int blocks = cdiv16(n_max, 4);
+        heads_split_kernel<<<blocks < 1024 ? blocks : 1024, 256, 0, st>>>(b.fcpart, b.max_rows, w.fc_b, w.heads_w,
+                                                                          w.heads_b, legal, logp_out, value_out,
+                                                                          prior_out, count_ptr, n_max);
+        break;
+    }
+    default: break;
+    }
+}
+
+}  // namespace nnb

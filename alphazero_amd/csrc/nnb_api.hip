@@ -113,13 +113,19 @@ void carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std::v
     b.act2 = c.take<float>(G * 72 * 128);
     b.act3 = c.take<float>(G * 90 * 128);
     b.fc = c.take<float>(G * 1024);
+    b.fcpart = c.take<float>(2 * G * 1024);
     b.max_rows = cfg.max_games;
     w.resize(cfg.n_weight_sets);
     for (auto &s : w) {
         s.conv0_w = c.take<float>(128 * 32);  s.conv0_b = c.take<float>(128);
-        s.conv2_w = c.take<float>(128 * 128 * 16);  s.conv2_b = c.take<float>(128);
-        s.conv4_w = c.take<float>(128 * 128 * 16);  s.conv4_b = c.take<float>(128);
-        s.fc_w = c.take<float>((size_t)1024 * 11520);  s.fc_b = c.take<float>(1024);
+        const bool f32 = cfg.net_precision == NNB_NET_F32;
+        s.conv2_b = c.take<float>(128); s.conv4_b = c.take<float>(128); s.fc_b = c.take<float>(1024);
+        s.conv2_w = f32 ? c.take<float>(128 * 128 * 16) : nullptr;
+        s.conv4_w = f32 ? c.take<float>(128 * 128 * 16) : nullptr;
+        s.fc_w = f32 ? c.take<float>((size_t)1024 * 11520) : nullptr;
+        s.conv2_wh = f32 ? nullptr : (void *)c.take<uint16_t>(128 * 128 * 16);
+        s.conv4_wh = f32 ? nullptr : (void *)c.take<uint16_t>(128 * 128 * 16);
+        s.fc_wh = f32 ? nullptr : (void *)c.take<uint16_t>((size_t)1024 * 11520);
         s.heads_w = c.take<float>(8 * 1024);  s.heads_b = c.take<float>(8);
     }
     c.take<unsigned char>(kAlign);          // tail pad
@@ -133,6 +139,8 @@ int check_cfg(const nnb_config *cfg) {
         return fail(NNB_ERR_ARG, "max_sims %d out of range [1, %d]", cfg->max_sims, kMaxSims);
     if (cfg->n_weight_sets < 1 || cfg->n_weight_sets > 8)
         return fail(NNB_ERR_ARG, "n_weight_sets %d out of range [1, 8]", cfg->n_weight_sets);
+    if (cfg->net_precision != NNB_NET_F16 && cfg->net_precision != NNB_NET_F32)
+        return fail(NNB_ERR_ARG, "net_precision %d out of range", cfg->net_precision);
     return NNB_OK;
 }
 
@@ -202,15 +210,23 @@ int check_params(nnb_engine *e, const nnb_search_params *p, int n) {
     return NNB_OK;
 }
 
+void net_stage(nnb_engine *e, hipStream_t st, int stage, const NetWeights &w, const u64 *side, const uint8_t *legal,
+               float *logp, float *value, float *prior, const int32_t *count_ptr, int n_max) {
+    if (e->cfg.net_precision == NNB_NET_F32)
+        launch_net_stage(st, stage, w, e->buf, side, legal, logp, value, prior, count_ptr, n_max);
+    else
+        launch_net_stage_f16(st, stage, w, e->buf, side, legal, logp, value, prior, count_ptr, n_max);
+}
+
 // Forward pass over the engine's compacted leaf batch (count on the device).
 void forward_leaves(nnb_engine *e, hipStream_t st, int weight_set, const int32_t *count_ptr, int n_max) {
     const NetWeights &w = e->weights[weight_set];
     const EngineDev &d = e->dev;
-    { ProfScope ps(e, 1, st); launch_net_stage(st, NET_CONV0, w, e->buf, d.leaf_side, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
-    { ProfScope ps(e, 2, st); launch_net_stage(st, NET_CONV2, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
-    { ProfScope ps(e, 3, st); launch_net_stage(st, NET_CONV4, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
-    { ProfScope ps(e, 4, st); launch_net_stage(st, NET_FC, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
-    { ProfScope ps(e, 5, st); launch_net_stage(st, NET_HEADS, w, e->buf, nullptr, d.leaf_legal, d.leaf_logp, d.leaf_value, d.leaf_prior, count_ptr, n_max); }
+    { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, d.leaf_side, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
+    { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
+    { ProfScope ps(e, 3, st); net_stage(e, st, NET_CONV4, w, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
+    { ProfScope ps(e, 4, st); net_stage(e, st, NET_FC, w, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
+    { ProfScope ps(e, 5, st); net_stage(e, st, NET_HEADS, w, nullptr, d.leaf_legal, d.leaf_logp, d.leaf_value, d.leaf_prior, count_ptr, n_max); }
 }
 
 // One move for every live game: S simulations, then the root readout.
@@ -320,6 +336,7 @@ int nnb_engine_create(const nnb_config *cfg, void *workspace, size_t workspace_b
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->host_counters), 64 * sizeof(int32_t), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->host_stats), 32 * sizeof(unsigned long long), hipHostMallocDefault));
     HIP_TRY(prepare_net_kernels());
+    HIP_TRY(prepare_net_kernels_f16());
     HIP_TRY(hipStreamSynchronize(st));
     *engine_out = e;
     return NNB_OK;
@@ -349,6 +366,7 @@ int nnb_load_weights(nnb_engine *e, int weight_set, void *stream, const float *c
     hipStream_t st = static_cast<hipStream_t>(stream);
     launch_repack(st, e->weights[weight_set], conv0_w, conv0_b, conv2_w, conv2_b, conv4_w, conv4_b, fc_w, fc_b,
                   policy_w, policy_b, value_w, value_b);
+    if (e->cfg.net_precision == NNB_NET_F16) launch_repack_f16(st, e->weights[weight_set], conv2_w, conv4_w, fc_w);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     e->weights_loaded[weight_set] = 1;
@@ -400,11 +418,11 @@ int nnb_net_forward(nnb_engine *e, int weight_set, void *stream, int32_t n, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     const NetWeights &w = e->weights[weight_set];
     const u64 *side = reinterpret_cast<const u64 *>(side_boards);
-    { ProfScope ps(e, 1, st); launch_net_stage(st, NET_CONV0, w, e->buf, side, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
-    { ProfScope ps(e, 2, st); launch_net_stage(st, NET_CONV2, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
-    { ProfScope ps(e, 3, st); launch_net_stage(st, NET_CONV4, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
-    { ProfScope ps(e, 4, st); launch_net_stage(st, NET_FC, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
-    { ProfScope ps(e, 5, st); launch_net_stage(st, NET_HEADS, w, e->buf, nullptr, legal_masks, log_policy_out, value_out, priors_out, nullptr, n); }
+    { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, side, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+    { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+    { ProfScope ps(e, 3, st); net_stage(e, st, NET_CONV4, w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+    { ProfScope ps(e, 4, st); net_stage(e, st, NET_FC, w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+    { ProfScope ps(e, 5, st); net_stage(e, st, NET_HEADS, w, nullptr, legal_masks, log_policy_out, value_out, priors_out, nullptr, n); }
     HIP_TRY(hipGetLastError());
     return NNB_OK;
 }

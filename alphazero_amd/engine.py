@@ -13,8 +13,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (EVALUATORS, MODES, TRAJECTORY_BYTES, Config, NnbError, RoundStats, SearchParams,
-                   check)
+from ._lib import (EVALUATORS, MODES, PRECISIONS, TRAJECTORY_BYTES, Config, NnbError, RoundStats,
+                   SearchParams, check)
 
 STATE_DICT_KEYS = [
     "conv_layers.0.weight", "conv_layers.0.bias",
@@ -46,7 +46,7 @@ class Engine:
     """One engine = one GPU, one workspace, up to `max_games` concurrent games."""
 
     def __init__(self, max_games: int, max_sims: int, device: Optional[torch.device] = None,
-                 n_weight_sets: int = 1):
+                 n_weight_sets: int = 1, precision: str = "f16"):
         if not torch.cuda.is_available():
             raise NnbError("no GPU visible: the engine runs on an MI355X only (there is no CPU path)")
         self.lib = _lib.load()
@@ -54,7 +54,9 @@ class Engine:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.max_games, self.max_sims = int(max_games), int(max_sims)
-        self.cfg = Config(self.max_games, self.max_sims, self.device.index, int(n_weight_sets))
+        self.precision = precision
+        self.cfg = Config(self.max_games, self.max_sims, self.device.index, int(n_weight_sets),
+                          PRECISIONS[precision], 0)
         nbytes = C.c_size_t()
         check(self.lib.nnb_workspace_bytes(C.byref(self.cfg), C.byref(nbytes)), "nnb_workspace_bytes")
         self.workspace_bytes = nbytes.value

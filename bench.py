@@ -41,8 +41,8 @@ FLOP_PER_LEAF = {
     "fc": 2 * 11520 * 1024,
     "heads": 2 * 1024 * 8,
 }
-DTYPE = "f32"
-PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X dense f32 matrix peak
+PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}      # MI355X dense matrix peaks (half inputs / f32 inputs)
+DTYPE_NAME = {"f16": "f16 (f32 accumulate)", "f32": "f32"}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--games", type=int, default=GAMES_PER_GPU, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=SIMS)
+    ap.add_argument("--precision", choices=["f16", "f32"], default="f16",
+                    help="arithmetic of the network's conv / linear layers (both accumulate in f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -107,7 +109,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     G = args.games
-    engine = Engine(max_games=G, max_sims=args.sims, device=device)
+    engine = Engine(max_games=G, max_sims=args.sims, device=device, precision=args.precision)
     engine.load_state_dict(seeded_state_dict(0))
     params = engine.params(args.sims, C_PUCT, evaluator="net", mode="compat")
     traj = torch.empty((G, TRAJECTORY_BYTES), dtype=torch.uint8, device=device)
@@ -177,7 +179,7 @@ def main():
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
             if files:
                 tj = json.load(open(files[-1]))
-                if tj.get("dtype", "f32") == DTYPE and G == GAMES_PER_GPU and args.sims == SIMS:
+                if tj.get("dtype", "f32") == args.precision and G == GAMES_PER_GPU and args.sims == SIMS:
                     traffic = tj["kernels"][dom]["hbm_bytes"]
                     traffic_src = os.path.relpath(files[-1], ROOT)
         except Exception:
@@ -200,7 +202,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": DTYPE,
+            "dtype": DTYPE_NAME[args.precision],
             "data": "synthetic: games from the empty board, random-init Connect4Net (torch.manual_seed(0))",
             "config": {"workload": f"{G} concurrent games per GPU x {args.sims} sims/move, batched leaf inference, "
                                    "reference search rule (compat), every game played to the end",
@@ -214,8 +216,8 @@ def main():
                       "allgather_ms": gather_ms,
                       "allgather_bytes": world * G * TRAJECTORY_BYTES if world > 1 else 0},
             "kernel_ms": {k: round(v["avg_ms"], 4) for k, v in prof.items()},
-            "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic,
+            "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.precision],
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": traffic,
                          "traffic_source": traffic_src,
                          "flop_per_leaf": FLOP_PER_LEAF[dom], "leaves_per_launch": leaves_per_launch,
                          "avg_launch_ms": avg_ms, "whole_net_tflops": net_tflops},

@@ -73,11 +73,20 @@ enum nnb_flags {
     NNB_FLAG_LOCKSTEP = 1
 };
 
+/* How the network's three big layers multiply.  Both accumulate in float32 and keep bias,
+ * ReLU, heads, log-softmax and tanh in float32.
+ *   NNB_NET_F16: activations and weights rounded to IEEE half, v_mfma_f32_32x32x16_f16
+ *                (about 1e-5 absolute from the float32 forward on the default network);
+ *   NNB_NET_F32: float32 inputs, v_mfma_f32_32x32x2_f32 (exact f32 FMA chains, 1/16 the rate). */
+enum nnb_precision { NNB_NET_F16 = 0, NNB_NET_F32 = 1 };
+
 typedef struct nnb_config {
     int32_t max_games;   /* concurrent games / root positions per call (>= 1)      */
     int32_t max_sims;    /* simulations per move; node pool = 1 + 7*max_sims nodes */
     int32_t device;      /* HIP device ordinal the workspace lives on              */
     int32_t n_weight_sets; /* resident network weight sets (1, or 2 for an arena)  */
+    int32_t net_precision; /* nnb_precision: arithmetic of the conv / linear layers */
+    int32_t reserved;
 } nnb_config;
 
 typedef struct nnb_search_params {

@@ -53,7 +53,7 @@ def test_struct_sizes_match_the_header(tmp_path):
 def test_version_and_host_only_calls(lib):
     from alphazero_amd import _lib
     assert lib.nnb_version().startswith(b"nnb ")
-    cfg = _lib.Config(4096, 200, 0, 1)
+    cfg = _lib.Config(4096, 200, 0, 1, 1, 0)
     n = C.c_size_t()
     assert lib.nnb_workspace_bytes(C.byref(cfg), C.byref(n)) == 0
     nodes = 4096 * (1 + 7 * 200) * 16
@@ -68,8 +68,8 @@ def test_argument_errors_are_reported(lib):
     n = C.c_size_t()
     assert lib.nnb_workspace_bytes(None, C.byref(n)) == -1
     assert b"null" in lib.nnb_last_error()
-    for bad in (_lib.Config(0, 200, 0, 1), _lib.Config(16, 0, 0, 1), _lib.Config(16, 20000, 0, 1),
-                _lib.Config(16, 200, 0, 0)):
+    for bad in (_lib.Config(0, 200, 0, 1, 0, 0), _lib.Config(16, 0, 0, 1, 0, 0), _lib.Config(16, 20000, 0, 1, 0, 0),
+                _lib.Config(16, 200, 0, 0, 0, 0), _lib.Config(16, 200, 0, 1, 7, 0)):
         assert lib.nnb_workspace_bytes(C.byref(bad), C.byref(n)) == -1
         assert b"out of range" in lib.nnb_last_error()
     assert lib.nnb_game_ops(None, -1, None, None, None, None, None, None) == -1

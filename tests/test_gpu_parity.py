@@ -41,11 +41,20 @@ def oracle():
     return co, rp
 
 
-@pytest.fixture(scope="module")
-def seed0_engine(engine, oracle):
+@pytest.fixture(scope="module", params=["f16", "f32"])
+def seed0_engine(request, torch_mod, oracle):
+    """Engines with the seed-0 network loaded, one per network arithmetic: half inputs on
+    v_mfma_f32_32x32x16_f16 (the default) and float32 inputs on v_mfma_f32_32x32x2_f32."""
+    from alphazero_amd.engine import Engine
     _, rp = oracle
-    engine.load_state_dict(rp.seeded_state_dict(0))
-    return engine
+    eng = Engine(max_games=512, max_sims=200, precision=request.param)
+    eng.load_state_dict(rp.seeded_state_dict(0))
+    yield eng
+    eng.close()
+
+
+# max |device - reference CPU float32| allowed in practice per arithmetic (the task's bar is 1e-3)
+TIGHT = {"f32": 5e-5, "f16": 2e-4}
 
 
 def _random_positions(rp, co, n, seed, max_plies=36, allow_terminal=False):
@@ -293,9 +302,12 @@ def test_net_forward_golden(seed0_engine, oracle):
     assert np.abs(logp - z["log_policy"]).max() < NET_ATOL
     assert np.abs(value - z["value"]).max() < NET_ATOL
     assert np.abs(priors - z["priors"]).max() < NET_ATOL
-    # in practice the f32 matrix-core path is far tighter than the stated tolerance
-    assert np.abs(logp - z["log_policy"]).max() < 5e-5
-    assert np.abs(value - z["value"]).max() < 5e-5
+    # in practice both arithmetics are far tighter than the stated tolerance
+    tight = TIGHT[seed0_engine.precision]
+    assert np.abs(logp - z["log_policy"]).max() < tight
+    assert np.abs(value - z["value"]).max() < tight
+    print(seed0_engine.precision, "max |dlogp|", np.abs(logp - z["log_policy"]).max(),
+          "max |dvalue|", np.abs(value - z["value"]).max())
 
 
 def test_net_forward_planes_and_ragged_batches(seed0_engine, oracle, torch_mod):
@@ -308,8 +320,8 @@ def test_net_forward_planes_and_ragged_batches(seed0_engine, oracle, torch_mod):
     for n in (1, 2, 3, 5, 127, 129, 256):          # ragged tails of every kernel's tile
         lp, v = seed0_engine.net_forward_planes(planes[:n])
         assert lp.shape == (n, 7) and v.shape == (n, 1)
-        assert (lp.cpu() - lp_ref[:n]).abs().max() < 5e-5
-        assert (v.cpu() - v_ref[:n]).abs().max() < 5e-5
+        assert (lp.cpu() - lp_ref[:n]).abs().max() < TIGHT[seed0_engine.precision]
+        assert (v.cpu() - v_ref[:n]).abs().max() < TIGHT[seed0_engine.precision]
 
 
 def test_net_search_matches_cpu_reference_game(seed0_engine, oracle, net_golden_meta):
@@ -329,5 +341,7 @@ def test_net_search_matches_cpu_reference_game(seed0_engine, oracle, net_golden_
                                                    seed0_engine.params(100, 1.4, evaluator="net"))
     agree = sum(int(visits[i].tolist() == g["visits"][i]) for i in range(len(boards)))
     assert visits.sum(axis=1).tolist() == [99] * len(boards)
-    assert agree >= int(0.75 * len(boards)), (agree, len(boards))
+    print(seed0_engine.precision, "plies with identical visit vectors:", agree, "of", len(boards))
+    need = 0.75 if seed0_engine.precision == "f32" else 0.5
+    assert agree >= int(need * len(boards)), (agree, len(boards))
     assert action.tolist()[:4] == g["moves"][:4]
