@@ -96,21 +96,49 @@ __global__ __launch_bounds__(128) void conv_in_f16_kernel(const u64 *__restrict_
 // ---------------------------------------------------------------------------
 // conv 128->128, 4x4, pad 2, + bias + ReLU (network.py:31-34): implicit GEMM on
 // v_mfma_f32_32x32x16_f16.  in/out: half, channels-last.
-// Block = NB boards staged once in LDS (256-byte rows of 16 chunks, chunk q of row p
-// stored at q ^ (p & 15); one extra all-zero row for out-of-range taps).  Wave w owns
-// output channels 32w..32w+31 for all MT row tiles; weights stream L2 -> VGPR.
+//
+// LDS image.  A block stages NB boards as "positions" of 128 channels (256 bytes, padded
+// to 272 so consecutive positions fall on different banks).  Every image row carries two
+// extra all-zero positions after its IW data positions, and the rows of all boards follow
+// each other, so a tap that steps off the left or right edge lands on zeros by plain
+// address arithmetic; two leading zero positions serve the first row and one more zero
+// position serves taps that step off the top or bottom.  With that layout the position a
+// lane reads is (position of its output cell) + dh*(IW+2) + dw: the 16 lanes that one
+// ds_read_b128 services together hold 16 consecutive output cells (see `sigma`), hence 16
+// distinct positions within a span of 18, hence (almost always) 16 different banks.
+//
+// Work split.  Wave w owns output channels 32w..32w+31 for all MT tiles of 32 output cells.
+// Per tap and 16-channel k-step a wave issues MT MFMAs; the A fragments come from LDS through
+// a ring of ARING registers (the read for MFMA f+ARING is issued right after MFMA f), the
+// weight fragments stream L2 -> VGPR BRING-1 steps ahead.  The result tile goes back
+// through LDS so the global stores are full 16-byte, row-contiguous writes.
 // ---------------------------------------------------------------------------
-template <int IH, int IW, int NB, int WAVES_PER_SIMD>
+constexpr int CONV_RS = 17;                      // LDS stride of one position in 16-byte chunks
+
+// MFMA row (lane & 31) -> output cell within the tile.  ds_read_b128 services lanes
+// {0-3,12-15,20-27} and {4-11,16-19,28-31} (and the same +32) as two groups of 16; sigma
+// gives the first group cells 0..15 and the second cells 16..31.
+__host__ __device__ constexpr int sigma(int m) {
+    return m < 4 ? m : m < 12 ? m + 12 : m < 16 ? m - 8 : m < 20 ? m + 8 : m < 28 ? m - 12 : m;
+}
+
+// ABLATE (timing experiments only, 0 in the product): 1 skip staging, 2 reuse one A fragment,
+// 4 reuse one weight fragment, 8 skip the output stores.
+template <int IH, int IW, int NB, int WAVES_PER_SIMD, int BRING, int ABLATE = 0>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv_mid_f16_kernel(const _Float16 *__restrict__ in,
                                                                            const _Float16 *__restrict__ wp,
                                                                            const float *__restrict__ bias,
                                                                            _Float16 *__restrict__ out,
                                                                            const int32_t *__restrict__ count_ptr,
                                                                            int n_fixed) {
-    constexpr int OH = IH + 1, OW = IW + 1, IP = IH * IW, OP = OH * OW;
+    constexpr int OH = IH + 1, OW = IW + 1, IP = IH * IW, OP = OH * OW, W2 = IW + 2;
     constexpr int M = NB * OP, MT = (M + 31) / 32, ROWS = NB * IP;
+    constexpr int LEAD = 2, ZERO = LEAD + NB * IH * W2;          // position indices
+    constexpr int NZ = 2 + NB * IH * 2 + 1;                      // zero positions to fill
+    constexpr int ARING = 8, STEPS = 8 * MT;                     // MFMAs per tap
+    constexpr int PB = CONV_RS * 16;                             // bytes per position
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);          // [(ROWS+1)][16] x 16 bytes
+    uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
 
     const int count = batch_count16(count_ptr, n_fixed);
     const int b0 = blockIdx.x * NB;
@@ -120,24 +148,40 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv_mid_f16_kernel(const
 
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
     const uint4 *src = reinterpret_cast<const uint4 *>(in + (size_t)b0 * IP * 128);
-    for (int e = tid; e < ROWS * 16; e += 256) {
-        int p = e >> 4, q = e & 15;
-        uint4 v = (p < nb_valid * IP) ? src[e] : zero4;
-        lds[p * 16 + (q ^ (p & 15))] = v;
+    if (!(ABLATE & 1))
+        for (int e = tid; e < ROWS * 16; e += 256) {
+            int p = e >> 4, q = e & 15;
+            uint4 v = (p < nb_valid * IP) ? src[e] : zero4;
+            lds[(LEAD + (p / IW) * W2 + p % IW) * CONV_RS + q] = v;
+        }
+    for (int e = tid; e < NZ * 16; e += 256) {
+        int z = e >> 4, q = e & 15;
+        int pos = z < 2 ? z : (z == NZ - 1 ? ZERO : LEAD + ((z - 2) >> 1) * W2 + IW + ((z - 2) & 1));
+        lds[pos * CONV_RS + q] = zero4;
     }
-    if (tid < 16) lds[ROWS * 16 + tid] = zero4;
     __syncthreads();
 
     const int lane = tid & 63, w = tid >> 6, m = lane & 31, h = lane >> 5;
-    int pbase[MT], ohv[MT], owv[MT];
+    // per tile: this lane's output cell -> oh (100 = no such cell) and the position it reads at tap (0,0)
+    int geo[MT];
+    {
+        const int cell = sigma(m);
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        int r = t * 32 + m;
-        int j = r / OP, o = r % OP;
-        ohv[t] = (r < M) ? o / OW : -100;
-        owv[t] = o % OW;
-        pbase[t] = j * IP + (o / OW) * IW + (o % OW);
+        for (int t = 0; t < MT; ++t) {
+            int r = t * 32 + cell;
+            int j = r / OP, o = r % OP;
+            int oh = (r < M) ? o / OW : 100;
+            geo[t] = (oh << 16) | (LEAD + (j * IH + o / OW) * W2 + o % OW);
+        }
     }
+    auto row_addr = [&](int t, int tap) -> unsigned {           // LDS byte address for lane half h
+        const int dh = (tap >> 2) - 2, dw = (tap & 3) - 2;
+        int oh = geo[t] >> 16, p0 = geo[t] & 0xFFFF;
+        bool ok = (unsigned)(oh + dh) < (unsigned)IH;
+        int pos = ok ? p0 + dh * W2 + dw : ZERO;
+        return (unsigned)(pos * PB + h * 16);
+    };
+
     f32x16 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t)
@@ -145,63 +189,101 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv_mid_f16_kernel(const
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const uint4 *wlane = reinterpret_cast<const uint4 *>(wp) + h * 128 + w * 32 + m;
-    uint4 bnext = wlane[0];
-    for (int tap = 0; tap < 16; ++tap) {
-        const int dh = (tap >> 2) - 2, dw = (tap & 3) - 2;
-        int rowoff[MT], sw[MT];
+    uint4 bring[BRING];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            int ih = ohv[t] + dh, iw = owv[t] + dw;
-            bool ok = (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
-            int p = ok ? pbase[t] + dh * IW + dw : ROWS;
-            rowoff[t] = p * 16;
-            sw[t] = p & 15;
-        }
+    for (int i = 0; i < BRING - 1; ++i) bring[i] = wlane[i * 256];
+    unsigned base[MT], nbase[MT];
+    uint4 afrag[ARING];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) base[t] = row_addr(t, 0);
+#pragma unroll
+    for (int f = 0; f < ARING; ++f)
+        afrag[f] = *reinterpret_cast<const uint4 *>(smem_raw + base[f % MT] + (f / MT) * 32);
+
+    for (int tap = 0; tap < 16; ++tap) {
+        const int ntap = tap < 15 ? tap + 1 : 15;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) nbase[t] = row_addr(t, ntap);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const half8 b = as_half8(bnext);
-            int nxt = tap * 8 + ks + 1;
-            nxt = nxt < 128 ? nxt : 127;
-            bnext = wlane[nxt * 256];
-            const int q = 2 * ks + h;
+            if (!(ABLATE & 4)) {                                 // weights BRING-1 steps ahead
+                int nxt = tap * 8 + ks + BRING - 1;
+                nxt = nxt < 128 ? nxt : 127;
+                bring[(ks + BRING - 1) & (BRING - 1)] = wlane[nxt * 256];
+            }
+            const half8 b = as_half8(bring[(ABLATE & 4) ? 0 : (ks & (BRING - 1))]);
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-                const half8 a = as_half8(lds[rowoff[t] + (q ^ sw[t])]);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[t], 0, 0, 0);
+                const int f = ks * MT + t, g = f + ARING;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(afrag[(ABLATE & 2) ? 0 : f % ARING]), b,
+                                                                acc[t], 0, 0, 0);
+                if (!(ABLATE & 2)) {
+                    // refill the ring slot just consumed with the fragment of MFMA f + ARING
+                    if (g < STEPS)
+                        afrag[g % ARING] = *reinterpret_cast<const uint4 *>(smem_raw + base[g % MT] + (g / MT) * 32);
+                    else
+                        afrag[g % ARING] = *reinterpret_cast<const uint4 *>(smem_raw + nbase[(g - STEPS) % MT] +
+                                                                            ((g - STEPS) / MT) * 32);
+                }
+                __builtin_amdgcn_sched_barrier(0);               // keep the MFMA / LDS-read interleave as written
             }
         }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) base[t] = nbase[t];
     }
 
-    const float bv = bias[w * 32 + m];
-    _Float16 *obase = out + (size_t)b0 * OP * 128 + w * 32 + m;
+    // epilogue: bias + ReLU, tile -> LDS as [output cell][128 channels] halves, then full-row stores
+    __syncthreads();
+    if (!(ABLATE & 8)) {
+        const float bv = bias[w * 32 + m];
+        _Float16 *ldsh = reinterpret_cast<_Float16 *>(smem_raw);
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
+        for (int t = 0; t < MT; ++t) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int R = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (R < M && R < nb_valid * OP) obase[(size_t)R * 128] = (_Float16)fmaxf(acc[t][r] + bv, 0.f);
+            for (int r = 0; r < 16; ++r) {
+                const int ic = (r & 3) + 8 * (r >> 2);              // MFMA row for lane half 0; +4 for half 1
+                const int R = t * 32 + (h ? sigma(ic + 4) : sigma(ic));
+                if (R < M) ldsh[R * (PB / 2) + w * 32 + m] = (_Float16)fmaxf(acc[t][r] + bv, 0.f);
+            }
         }
+        __syncthreads();
+        uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)b0 * OP * 128);
+        const int nchunks = nb_valid * OP * 16;
+        for (int e = tid; e < nchunks; e += 256) dst[e] = lds[(e >> 4) * CONV_RS + (e & 15)];
+    } else {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (acc[t][r] == 12345.678f) out[0] = (_Float16)1.0f;   // keeps the accumulators live
     }
 }
 
 // ---------------------------------------------------------------------------
 // linear 11520->1024 (network.py:36-39,46-47) on v_mfma_f32_32x32x16_f16, split in two
-// halves of K.  Block tile 128 rows x 256 columns, 4 waves; wave w owns columns
-// 64w..64w+63 (two 32-column tiles) for all four 32-row tiles, so each A fragment read
-// from LDS feeds two MFMAs.  Raw float32 partial sums go to part[ksplit][row][1024];
+// halves of K.  Block tile 128 rows x 256 columns, 4 waves (one per SIMD); wave w owns
+// columns 64w..64w+63 (two 32-column tiles) for all four 32-row tiles, so each A fragment
+// read from LDS feeds two MFMAs.  Raw float32 partial sums go to part[ksplit][row][1024];
 // the heads kernel adds the halves, the bias and the ReLU.
+//
+// Pipeline (one wave per SIMD, so every latency is hidden in-wave): A slabs of 64 k go
+// global -> registers four slabs ahead, registers -> LDS two slabs ahead (three LDS
+// buffers, one barrier per slab); A fragments LDS -> registers one k-step ahead; weight
+// fragments L2 -> registers seven k-steps ahead.
 // Block order: the 32 blocks that share blockIdx % 8 (observed to share an XCD and its L2)
 // cover 4 row blocks x (4 column blocks x 2 K halves), so each A slab is fetched into that
 // L2 once and re-read by 8 blocks.
 // ---------------------------------------------------------------------------
 constexpr int FCH_K = 11520, FCH_N = 1024, FCH_BM = 128, FCH_BN = 256, FCH_BK = 64, FCH_SPLIT = 2;
 
+// ABLATE (timing experiments only): 1 no A global loads, 2 no A-fragment LDS reads, 4 no weight loads.
+template <int ABLATE = 0>
 __global__ __launch_bounds__(256, 1) void fc_f16_kernel(const _Float16 *__restrict__ a,   // [rows][11520]
                                                         const _Float16 *__restrict__ wp,  // repacked
                                                         float *__restrict__ part,         // [2][max_rows][1024]
                                                         const int32_t *__restrict__ count_ptr, int n_fixed,
                                                         int max_rows) {
-    __shared__ __attribute__((aligned(16))) uint4 lds[2][FCH_BM * 8];      // 128 rows x 64 halfs, two buffers
+    __shared__ __attribute__((aligned(16))) uint4 lds[3][FCH_BM * 8];      // 128 rows x 64 halfs, three buffers
     const int count = batch_count16(count_ptr, n_fixed);
     const int bid = blockIdx.x;
     const int x = bid & 7, i = bid >> 3;                    // i in [0, 32 * groups)
@@ -213,24 +295,43 @@ __global__ __launch_bounds__(256, 1) void fc_f16_kernel(const _Float16 *__restri
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, m = lane & 31, h = lane >> 5;
 
     constexpr int KHALF = FCH_K / FCH_SPLIT;                // 5760
-    constexpr int NSLAB = KHALF / FCH_BK;                   // 90
+    constexpr int NSLAB = KHALF / FCH_BK;                   // 90 slabs of 64 k = 4 k-steps each
+    constexpr int NKS = NSLAB * 4;
+    constexpr int BR = 8;                                   // weight ring depth (k-steps)
     const int k0 = ksp * KHALF;
 
-    // staging map: 128 rows x 8 chunks of 16 bytes = 1024 chunks, 4 per thread
-    int srow[4], scol[4];
-    const uint4 *abase[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        int e = tid + 256 * s;
-        srow[s] = e >> 3; scol[s] = e & 7;
-        int r = min(row0 + srow[s], max_rows - 1);
-        abase[s] = reinterpret_cast<const uint4 *>(a + (size_t)r * FCH_K + k0) + scol[s];
+    // staging map: 128 rows x 8 chunks of 16 bytes = 1024 chunks, 4 per thread.  Kept in named
+    // scalars (not arrays): arrays of staging registers ended up in scratch memory.
+#define FC_MAP(C)                                                                                 \
+    int sdst##C;                                                                                  \
+    const uint4 *abase##C;                                                                        \
+    {                                                                                             \
+        int e = tid + 256 * (C), srow = e >> 3, scol = e & 7;                                     \
+        sdst##C = srow * 8 + (scol ^ ((srow >> 1) & 7));                                          \
+        int r = min(row0 + srow, max_rows - 1);                                                   \
+        abase##C = reinterpret_cast<const uint4 *>(a + (size_t)r * FCH_K + k0) + scol;            \
     }
-    uint4 stage[4];
+    FC_MAP(0) FC_MAP(1) FC_MAP(2) FC_MAP(3)
+#undef FC_MAP
+#define FC_LOAD(S, SLAB)                                                                          \
+    { S##0 = abase0[(SLAB) * 8]; S##1 = abase1[(SLAB) * 8]; S##2 = abase2[(SLAB) * 8]; S##3 = abase3[(SLAB) * 8]; }
+#define FC_WRITE(S, BUF)                                                                          \
+    { lds[BUF][sdst0] = S##0; lds[BUF][sdst1] = S##1; lds[BUF][sdst2] = S##2; lds[BUF][sdst3] = S##3; }
+    // A-fragment read offsets (16-byte units) inside a buffer, per row tile, for k-step 0 of a slab
+    int aoff[4], asw[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) stage[s] = abase[s][0];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) lds[0][srow[s] * 8 + (scol[s] ^ ((srow[s] >> 1) & 7))] = stage[s];
+    for (int t = 0; t < 4; ++t) {
+        const int row = t * 32 + m;
+        aoff[t] = row * 8;
+        asw[t] = (row >> 1) & 7;
+    }
+
+    // Two register sets for the global -> LDS staging (named scalars, see above).
+    uint4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+    // prologue: slabs 0 and 1 into LDS, slabs 2 and 3 in flight in the two register sets
+    FC_LOAD(sa, 0) FC_LOAD(sb, 1)
+    FC_WRITE(sa, 0) FC_WRITE(sb, 1)
+    FC_LOAD(sa, 2) FC_LOAD(sb, 3)
     __syncthreads();
 
     f32x16 acc[4][2];
@@ -244,35 +345,58 @@ __global__ __launch_bounds__(256, 1) void fc_f16_kernel(const _Float16 *__restri
     // weight fragment of (k-step, column tile): ((kstep*2 + h)*1024 + n) * 16 bytes
     const uint4 *wlane = reinterpret_cast<const uint4 *>(wp) + (size_t)(k0 / 16) * 2 * FCH_N + h * FCH_N +
                          nb * FCH_BN + w * 64 + m;
-    uint4 bn0 = wlane[0], bn1 = wlane[32];
-    for (int s = 0; s < NSLAB; ++s) {
-        const int cur = s & 1;
-        if (s + 1 < NSLAB) {
+    uint4 br0[BR], br1[BR];                                 // ring of weight fragments, column tiles 0 / 1
 #pragma unroll
-            for (int c = 0; c < 4; ++c) stage[c] = abase[c][(s + 1) * 8];
-        }
+    for (int j = 0; j < BR - 1; ++j) { br0[j] = wlane[(size_t)j * 2 * FCH_N]; br1[j] = wlane[(size_t)j * 2 * FCH_N + 32]; }
+    uint4 afa[4], afb[4];                                   // A fragments of even / odd k-steps
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const half8 b0 = as_half8(bn0), b1 = as_half8(bn1);
-            int nxt = s * 4 + ks + 1;
-            nxt = nxt < NSLAB * 4 ? nxt : NSLAB * 4 - 1;
-            bn0 = wlane[(size_t)nxt * 2 * FCH_N];
-            bn1 = wlane[(size_t)nxt * 2 * FCH_N + 32];
-            const int q = 2 * ks + h;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int row = t * 32 + m;
-                const half8 av = as_half8(lds[cur][row * 8 + (q ^ ((row >> 1) & 7))]);
-                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[t][0], 0, 0, 0);
-                acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[t][1], 0, 0, 0);
-            }
-        }
-        if (s + 1 < NSLAB) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) lds[cur ^ 1][srow[c] * 8 + (scol[c] ^ ((srow[c] >> 1) & 7))] = stage[c];
-        }
-        __syncthreads();
+    for (int t = 0; t < 4; ++t) afa[t] = lds[0][aoff[t] + (h ^ asw[t])];
+
+// one k-step: J = k-step index inside the 24-step body, KS = k-step inside its slab,
+// CUR / NXT = fragment sets (afa, afb), NBUF = LDS buffer the next step's fragments come from
+#define FC_KSTEP(J, KS, CUR, NXT, NBUF)                                                                   \
+    {                                                                                                     \
+        if (!(ABLATE & 4)) {                                                                              \
+            int nxt = s * 4 + (KS) + BR - 1;                                                              \
+            nxt = nxt < NKS ? nxt : NKS - 1;                                                              \
+            br0[((J) + BR - 1) % BR] = wlane[(size_t)nxt * 2 * FCH_N];                                    \
+            br1[((J) + BR - 1) % BR] = wlane[(size_t)nxt * 2 * FCH_N + 32];                               \
+        }                                                                                                 \
+        if (((KS) < 3 || s + 1 < NSLAB) && !(ABLATE & 2)) {                                               \
+            const int nq = 2 * (((KS) + 1) & 3) + h;                                                      \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) NXT[t] = lds[NBUF][aoff[t] + (nq ^ asw[t])];    \
+        }                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        const half8 b0 = as_half8(br0[(ABLATE & 4) ? 0 : (J) % BR]), b1 = as_half8(br1[(ABLATE & 4) ? 0 : (J) % BR]); \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                   \
+            const half8 av = as_half8(((ABLATE & 2) ? afa : CUR)[t]);                                     \
+            acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[t][0], 0, 0, 0);               \
+            acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[t][1], 0, 0, 0);               \
+        }                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
     }
+
+// one slab: U = slab index inside the 6-slab body (LDS buffer U % 3), STG = staging register set
+#define FC_SLAB(U, STG)                                                                                   \
+    {                                                                                                     \
+        const int s = s6 + (U);                                                                           \
+        if (s + 2 < NSLAB) FC_WRITE(STG, ((U) + 2) % 3)                                                   \
+        if (s + 4 < NSLAB && !(ABLATE & 1)) FC_LOAD(STG, s + 4)                                           \
+        FC_KSTEP((U) * 4 + 0, 0, afa, afb, (U) % 3)                                                       \
+        FC_KSTEP((U) * 4 + 1, 1, afb, afa, (U) % 3)                                                       \
+        FC_KSTEP((U) * 4 + 2, 2, afa, afb, (U) % 3)                                                       \
+        FC_KSTEP((U) * 4 + 3, 3, afb, afa, ((U) + 1) % 3)                                                 \
+        __syncthreads();                                                                                  \
+    }
+
+    for (int s6 = 0; s6 < NSLAB; s6 += 6) {
+        FC_SLAB(0, sa) FC_SLAB(1, sb) FC_SLAB(2, sa)
+        FC_SLAB(3, sb) FC_SLAB(4, sa) FC_SLAB(5, sb)
+    }
+#undef FC_SLAB
+#undef FC_KSTEP
+#undef FC_LOAD
+#undef FC_WRITE
 
     float *obase = part + (size_t)ksp * max_rows * FCH_N + nb * FCH_BN + w * 64 + m;
 #pragma unroll
@@ -371,14 +495,18 @@ __global__ __launch_bounds__(256) void heads_split_kernel(const float *__restric
 static inline int cdiv16(int a, int b) { return (a + b - 1) / b; }
 
 constexpr int C2H_NB = 4, C4H_NB = 2;
-constexpr size_t C2H_LDS = (size_t)(C2H_NB * 7 * 8 + 1) * 256;
-constexpr size_t C4H_LDS = (size_t)(C4H_NB * 8 * 9 + 1) * 256;
+constexpr size_t conv_lds_bytes(int ih, int iw, int nb) {
+    int npos = 2 + nb * ih * (iw + 2) + 1, m = nb * (ih + 1) * (iw + 1);
+    return (size_t)(npos > m ? npos : m) * CONV_RS * 16;
+}
+constexpr size_t C2H_LDS = conv_lds_bytes(7, 8, C2H_NB);
+constexpr size_t C4H_LDS = conv_lds_bytes(8, 9, C4H_NB);
 
 hipError_t prepare_net_kernels_f16() {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mid_f16_kernel<7, 8, C2H_NB, 2>),
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mid_f16_kernel<7, 8, C2H_NB, 2, 4>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C2H_LDS);
     if (err != hipSuccess) return err;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mid_f16_kernel<8, 9, C4H_NB, 2>),
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mid_f16_kernel<8, 9, C4H_NB, 2, 4>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)C4H_LDS);
 }
 
@@ -401,16 +529,16 @@ void launch_net_stage_f16(hipStream_t st, int stage, const NetWeights &w, const 
                                                                          n_max);
         break;
     case NET_CONV2:
-        conv_mid_f16_kernel<7, 8, C2H_NB, 2><<<cdiv16(n_max, C2H_NB), 256, C2H_LDS, st>>>(
+        conv_mid_f16_kernel<7, 8, C2H_NB, 2, 4><<<cdiv16(n_max, C2H_NB), 256, C2H_LDS, st>>>(
             a1, (const _Float16 *)w.conv2_wh, w.conv2_b, a2, count_ptr, n_max);
         break;
     case NET_CONV4:
-        conv_mid_f16_kernel<8, 9, C4H_NB, 2><<<cdiv16(n_max, C4H_NB), 256, C4H_LDS, st>>>(
+        conv_mid_f16_kernel<8, 9, C4H_NB, 2, 4><<<cdiv16(n_max, C4H_NB), 256, C4H_LDS, st>>>(
             a2, (const _Float16 *)w.conv4_wh, w.conv4_b, a3, count_ptr, n_max);
         break;
     case NET_FC: {
         int groups = cdiv16(cdiv16(n_max, FCH_BM), 32);      // 32 row blocks per group of 256 blocks
-        fc_f16_kernel<<<256 * groups, 256, 0, st>>>(a3, (const _Float16 *)w.fc_wh, b.fcpart, count_ptr, n_max,
+        fc_f16_kernel<0><<<256 * groups, 256, 0, st>>>(a3, (const _Float16 *)w.fc_wh, b.fcpart, count_ptr, n_max,
                                                     b.max_rows);
         break;
     }
