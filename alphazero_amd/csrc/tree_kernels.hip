@@ -393,23 +393,32 @@ __global__ void tree_init_kernel(EngineDev e, SearchDev p, int make_noise, int s
 //      is used up; terminal leaves are backed up on the spot (agent_code.py:182-186);
 //   3. (COMPAT) expand the leaf - the reference ignores priors; append the leaf's side
 //      boards to the compacted batch and remember the path for step 1 of the next launch.
-// Launch with 256 threads = 4 games per block, one wavefront per game.
+// Launch with 1024 threads = 16 games per block, one wavefront per game.
 // ---------------------------------------------------------------------------
-template <bool AZ>
-__global__ __launch_bounds__(256) void tree_step_kernel(EngineDev e, SearchDev p, int parity) {
-    const int lane = threadIdx.x & 63;
-    const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (blockIdx.x == 0 && threadIdx.x == 0) e.leaf_count[parity ^ 1] = 0;
-    if (g >= e.n_games) return;
-    if (!e.active[g]) return;
+constexpr int kStepGames = 16;                    // games (wavefronts) per block of the step kernel
 
+template <bool AZ>
+__global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e, SearchDev p, int parity) {
+    __shared__ int s_want[kStepGames];
+    __shared__ int s_base;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g = blockIdx.x * kStepGames + wv;
+    if (blockIdx.x == 0 && threadIdx.x == 0) e.leaf_count[parity ^ 1] = 0;
+    const bool live = g < e.n_games && e.active[g];
+    // leaf found by this wave (if any), kept in registers until the block has claimed its
+    // slots in the compacted batch with ONE atomic (one per game serialised on the counter)
+    bool want = false;
+    u64 leaf_me = 0, leaf_opp = 0;
+    unsigned leaf_legal_mask = 0;
+    int leaf_len = 0, leaf_path = 0;
+    int sims_done = 0, n_nodes = 0, depth_sum = 0, term_hits = 0;
+    if (live) {
     Node *pool = e.nodes + (size_t)g * e.pool_cap;
     float *prior = e.prior + (size_t)g * e.pool_cap;
-    int sims_done = e.sims_done[g];
-    int n_nodes = e.n_nodes[g];
+    sims_done = e.sims_done[g];
+    n_nodes = e.n_nodes[g];
     const int player = e.root_player[g];
     const u64 r1 = e.root_boards[2 * g], r2 = e.root_boards[2 * g + 1];
-    int depth_sum = 0, term_hits = 0, leaves = 0;
 
     int pend = e.pending[g];
     if (pend >= 0) {
@@ -460,29 +469,46 @@ __global__ __launch_bounds__(256) void tree_step_kernel(EngineDev e, SearchDev p
             continue;
         }
         if (!AZ) n_nodes += expand_compat(pool, node, n_nodes, legal, lane);
-        int slot = 0;
-        if (lane == 0) slot = atomicAdd(&e.leaf_count[parity], 1);
-        slot = __shfl(slot, 0);
-        if (lane == 0) {
-            // COMPAT: the leaf is encoded from the root mover's side at every depth
-            // (agent_code.py:85); AZ: from the side to move at the leaf
-            e.leaf_side[2 * slot] = mover == 1 ? c1 : c2;
-            e.leaf_side[2 * slot + 1] = mover == 1 ? c2 : c1;
-            e.leaf_legal[slot] = (uint8_t)legal;
-            e.path_len[g] = len;
-        }
-        e.path[g * kPathSlots + lane] = (uint16_t)mypath;
-        pend = slot;
-        ++leaves;
+        // COMPAT: the leaf is encoded from the root mover's side at every depth
+        // (agent_code.py:85); AZ: from the side to move at the leaf
+        want = true;
+        leaf_me = mover == 1 ? c1 : c2;
+        leaf_opp = mover == 1 ? c2 : c1;
+        leaf_legal_mask = legal;
+        leaf_len = len;
+        leaf_path = mypath;
         break;
     }
+    }   // live
 
+    if (lane == 0) s_want[wv] = want ? 1 : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int k = 0; k < kStepGames; ++k) total += s_want[k];
+        s_base = total ? atomicAdd(&e.leaf_count[parity], total) : 0;
+    }
+    __syncthreads();
+    if (!live) return;
+    int pend_out = -1;
+    if (want) {
+        int slot = s_base;
+        for (int k = 0; k < wv; ++k) slot += s_want[k];
+        if (lane == 0) {
+            e.leaf_side[2 * slot] = leaf_me;
+            e.leaf_side[2 * slot + 1] = leaf_opp;
+            e.leaf_legal[slot] = (uint8_t)leaf_legal_mask;
+            e.path_len[g] = leaf_len;
+        }
+        e.path[g * kPathSlots + lane] = (uint16_t)leaf_path;
+        pend_out = slot;
+    }
     if (lane == 0) {
         e.sims_done[g] = sims_done;
         e.n_nodes[g] = n_nodes;
-        e.pending[g] = pend;
+        e.pending[g] = pend_out;
         int32_t *st = e.game_stats + 4 * g;
-        st[0] += depth_sum; st[1] += term_hits; st[2] += leaves;
+        st[0] += depth_sum; st[1] += term_hits; st[2] += want ? 1 : 0;
     }
 }
 
@@ -726,8 +752,9 @@ void launch_tree_init(hipStream_t st, const EngineDev &e, const SearchDev &p, in
 }
 
 void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, int parity) {
-    if (p.mode == NNB_MODE_AZ) tree_step_kernel<true><<<cdiv(e.n_games, 4), 256, 0, st>>>(e, p, parity);
-    else tree_step_kernel<false><<<cdiv(e.n_games, 4), 256, 0, st>>>(e, p, parity);
+    const int blocks = cdiv(e.n_games, kStepGames);
+    if (p.mode == NNB_MODE_AZ) tree_step_kernel<true><<<blocks, kStepGames * 64, 0, st>>>(e, p, parity);
+    else tree_step_kernel<false><<<blocks, kStepGames * 64, 0, st>>>(e, p, parity);
 }
 
 hipError_t prepare_tree_fused(size_t lds_bytes) {
