@@ -52,48 +52,6 @@ __global__ void repack_fc_f16_kernel(const float *__restrict__ w, _Float16 *__re
 }
 
 // ---------------------------------------------------------------------------
-// Leaf encode fused with conv 2->128 (network.py:29-30), half output
-// [board][7][8][128].  The sums are formed in float32 exactly as in the f32 path.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void conv_in_f16_kernel(const u64 *__restrict__ side, const float *__restrict__ w,
-                                                          const float *__restrict__ bias, _Float16 *__restrict__ out,
-                                                          const int32_t *__restrict__ count_ptr, int n_fixed) {
-    const int count = batch_count16(count_ptr, n_fixed);
-    const int n = threadIdx.x;
-    float wr[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) wr[k] = w[n * 32 + k];
-    const float b = bias[n];
-    for (int board = blockIdx.x; board < count; board += gridDim.x) {
-        unsigned lo0 = __builtin_amdgcn_readfirstlane((unsigned)side[2 * board]);
-        unsigned hi0 = __builtin_amdgcn_readfirstlane((unsigned)(side[2 * board] >> 32));
-        unsigned lo1 = __builtin_amdgcn_readfirstlane((unsigned)side[2 * board + 1]);
-        unsigned hi1 = __builtin_amdgcn_readfirstlane((unsigned)(side[2 * board + 1] >> 32));
-        const u64 pl[2] = {((u64)hi0 << 32) | lo0, ((u64)hi1 << 32) | lo1};
-        _Float16 *o = out + (size_t)board * 56 * 128 + n;
-#pragma unroll
-        for (int oh = 0; oh < 7; ++oh) {
-#pragma unroll
-            for (int ow = 0; ow < 8; ++ow) {
-                float acc = b;
-#pragma unroll
-                for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-                    for (int kh = 0; kh < 4; ++kh)
-#pragma unroll
-                        for (int kw = 0; kw < 4; ++kw) {
-                            const int ih = oh + kh - 2, iw = ow + kw - 2;
-                            if (ih >= 0 && ih < 6 && iw >= 0 && iw < 7) {
-                                if ((pl[ci] >> (iw * 7 + (5 - ih))) & 1) acc += wr[(ci * 4 + kh) * 4 + kw];
-                            }
-                        }
-                o[(oh * 8 + ow) * 128] = (_Float16)fmaxf(acc, 0.0f);
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
 // conv 128->128, 4x4, pad 2, + bias + ReLU (network.py:31-34): implicit GEMM on
 // v_mfma_f32_32x32x16_f16.  in/out: half, channels-last.
 //
@@ -124,18 +82,27 @@ __host__ __device__ constexpr int sigma(int m) {
 
 // ABLATE (timing experiments only, 0 in the product): 1 skip staging, 2 reuse one A fragment,
 // 4 reuse one weight fragment, 8 skip the output stores.
-template <int IH, int IW, int NB, int WAVES_PER_SIMD, int BRING, int ABLATE = 0>
+//
+// FUSE_IN (first 128->128 layer only): the block's input is not read from memory but computed in
+// place - leaf encode (AlphaZeroAgent.preprocess, agent_code.py:76-89) and the 2->128 convolution
+// (network.py:29-30) straight from the side boards into the LDS image, as two k-steps of MFMAs
+// whose A operand is built from the board bits.
+template <int IH, int IW, int NB, int WAVES_PER_SIMD, int BRING, int ARING, bool FUSE_IN = false, int ABLATE = 0>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv_mid_f16_kernel(const _Float16 *__restrict__ in,
                                                                            const _Float16 *__restrict__ wp,
                                                                            const float *__restrict__ bias,
                                                                            _Float16 *__restrict__ out,
                                                                            const int32_t *__restrict__ count_ptr,
-                                                                           int n_fixed) {
+                                                                           int n_fixed,
+                                                                           const u64 *__restrict__ side = nullptr,
+                                                                           const float *__restrict__ w_in = nullptr,
+                                                                           const float *__restrict__ b_in = nullptr) {
     constexpr int OH = IH + 1, OW = IW + 1, IP = IH * IW, OP = OH * OW, W2 = IW + 2;
     constexpr int M = NB * OP, MT = (M + 31) / 32, ROWS = NB * IP;
     constexpr int LEAD = 2, ZERO = LEAD + NB * IH * W2;          // position indices
     constexpr int NZ = 2 + NB * IH * 2 + 1;                      // zero positions to fill
-    constexpr int ARING = 8, STEPS = 8 * MT;                     // MFMAs per tap
+    constexpr int STEPS = 8 * MT;                                // MFMAs per tap
+    static_assert(STEPS % ARING == 0, "ring depth must divide the MFMAs per tap");
     constexpr int PB = CONV_RS * 16;                             // bytes per position
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4 *lds = reinterpret_cast<uint4 *>(smem_raw);
@@ -147,13 +114,59 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv_mid_f16_kernel(const
     const int tid = threadIdx.x;
 
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    const uint4 *src = reinterpret_cast<const uint4 *>(in + (size_t)b0 * IP * 128);
-    if (!(ABLATE & 1))
-        for (int e = tid; e < ROWS * 16; e += 256) {
-            int p = e >> 4, q = e & 15;
-            uint4 v = (p < nb_valid * IP) ? src[e] : zero4;
-            lds[(LEAD + (p / IW) * W2 + p % IW) * CONV_RS + q] = v;
+    if constexpr (FUSE_IN) {
+        static_assert(IH == 7 && IW == 8, "the fused input layer produces 7x8 maps");
+        const int lane_ = tid & 63, w_ = tid >> 6, m_ = lane_ & 31, h_ = lane_ >> 5;
+        // weights of this wave's 32 output channels: k = plane*16 + kh*4 + kw, lane half h_ holds k%16 in [8h_, 8h_+8)
+        half8 bw[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) bw[pl][jj] = (_Float16)w_in[(w_ * 32 + m_) * 32 + 16 * pl + 8 * h_ + jj];
+        const float bv_in = b_in[w_ * 32 + m_];
+        _Float16 *ldsh_in = reinterpret_cast<_Float16 *>(smem_raw);
+        for (int j = 0; j < NB; ++j) {
+            const bool have = j < nb_valid;
+            const u64 planes[2] = {have ? side[2 * (b0 + j)] : 0, have ? side[2 * (b0 + j) + 1] : 0};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int pos = mt * 32 + m_, oh = pos >> 3, ow = pos & 7;     // output cell of this MFMA row
+                f32x16 c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    half8 a;
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const int ih = oh + 2 * h_ + rr - 2;                   // kh = 2h_ + rr
+                        // bits iw = 0..6 of reference row ih: stones at bit iw*7 + (5 - ih)
+                        u64 t = (unsigned)ih < 6u ? (planes[pl] >> (5 - ih)) & c4::kBottomMask : 0;
+                        unsigned row = (unsigned)((t * 0x41041041040ULL) >> 42) & 0x7F;
+                        unsigned nib = ((row << 2) >> ow) & 0xF;               // bit kw <-> iw = ow + kw - 2
+#pragma unroll
+                        for (int kw = 0; kw < 4; ++kw) a[rr * 4 + kw] = ((nib >> kw) & 1) ? (_Float16)1.0f : (_Float16)0.0f;
+                    }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bw[pl], c, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h_;
+                    if (p < IP)
+                        ldsh_in[(LEAD + (j * IH + p / IW) * W2 + p % IW) * (PB / 2) + w_ * 32 + m_] =
+                            (_Float16)fmaxf(c[r] + bv_in, 0.f);
+                }
+            }
         }
+    } else {
+        const uint4 *src = reinterpret_cast<const uint4 *>(in + (size_t)b0 * IP * 128);
+        if (!(ABLATE & 1))
+            for (int e = tid; e < ROWS * 16; e += 256) {
+                int p = e >> 4, q = e & 15;
+                uint4 v = (p < nb_valid * IP) ? src[e] : zero4;
+                lds[(LEAD + (p / IW) * W2 + p % IW) * CONV_RS + q] = v;
+            }
+    }
     for (int e = tid; e < NZ * 16; e += 256) {
         int z = e >> 4, q = e & 15;
         int pos = z < 2 ? z : (z == NZ - 1 ? ZERO : LEAD + ((z - 2) >> 1) * W2 + IW + ((z - 2) & 1));
@@ -503,10 +516,10 @@ constexpr size_t C2H_LDS = conv_lds_bytes(7, 8, C2H_NB);
 constexpr size_t C4H_LDS = conv_lds_bytes(8, 9, C4H_NB);
 
 hipError_t prepare_net_kernels_f16() {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mid_f16_kernel<7, 8, C2H_NB, 2, 4>),
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mid_f16_kernel<7, 8, C2H_NB, 2, 4, 4, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C2H_LDS);
     if (err != hipSuccess) return err;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mid_f16_kernel<8, 9, C4H_NB, 2, 4>),
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mid_f16_kernel<8, 9, C4H_NB, 2, 4, 12>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)C4H_LDS);
 }
 
@@ -521,19 +534,16 @@ void launch_net_stage_f16(hipStream_t st, int stage, const NetWeights &w, const 
                           const uint8_t *legal, float *logp_out, float *value_out, float *prior_out,
                           const int32_t *count_ptr, int n_max) {
     if (n_max <= 0) return;
-    _Float16 *a1 = reinterpret_cast<_Float16 *>(b.act1), *a2 = reinterpret_cast<_Float16 *>(b.act2),
-             *a3 = reinterpret_cast<_Float16 *>(b.act3);
+    _Float16 *a2 = reinterpret_cast<_Float16 *>(b.act2), *a3 = reinterpret_cast<_Float16 *>(b.act3);
     switch (stage) {
     case NET_CONV0:
-        conv_in_f16_kernel<<<n_max < 2048 ? n_max : 2048, 128, 0, st>>>(side, w.conv0_w, w.conv0_b, a1, count_ptr,
-                                                                         n_max);
-        break;
+        break;      // fused into the first 128->128 layer below
     case NET_CONV2:
-        conv_mid_f16_kernel<7, 8, C2H_NB, 2, 4><<<cdiv16(n_max, C2H_NB), 256, C2H_LDS, st>>>(
-            a1, (const _Float16 *)w.conv2_wh, w.conv2_b, a2, count_ptr, n_max);
+        conv_mid_f16_kernel<7, 8, C2H_NB, 2, 4, 4, true><<<cdiv16(n_max, C2H_NB), 256, C2H_LDS, st>>>(
+            nullptr, (const _Float16 *)w.conv2_wh, w.conv2_b, a2, count_ptr, n_max, side, w.conv0_w, w.conv0_b);
         break;
     case NET_CONV4:
-        conv_mid_f16_kernel<8, 9, C4H_NB, 2, 4><<<cdiv16(n_max, C4H_NB), 256, C4H_LDS, st>>>(
+        conv_mid_f16_kernel<8, 9, C4H_NB, 2, 4, 12><<<cdiv16(n_max, C4H_NB), 256, C4H_LDS, st>>>(
             a2, (const _Float16 *)w.conv4_wh, w.conv4_b, a3, count_ptr, n_max);
         break;
     case NET_FC: {

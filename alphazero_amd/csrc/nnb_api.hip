@@ -223,7 +223,7 @@ void forward_leaves(nnb_engine *e, hipStream_t st, int weight_set, const int32_t
     const NetWeights &w = e->weights[weight_set];
     const EngineDev &d = e->dev;
     { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, d.leaf_side, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
-    { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
+    { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, d.leaf_side, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
     { ProfScope ps(e, 3, st); net_stage(e, st, NET_CONV4, w, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
     { ProfScope ps(e, 4, st); net_stage(e, st, NET_FC, w, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
     { ProfScope ps(e, 5, st); net_stage(e, st, NET_HEADS, w, nullptr, d.leaf_legal, d.leaf_logp, d.leaf_value, d.leaf_prior, count_ptr, n_max); }
@@ -419,7 +419,7 @@ int nnb_net_forward(nnb_engine *e, int weight_set, void *stream, int32_t n, cons
     const NetWeights &w = e->weights[weight_set];
     const u64 *side = reinterpret_cast<const u64 *>(side_boards);
     { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, side, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
-    { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+    { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, side, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
     { ProfScope ps(e, 3, st); net_stage(e, st, NET_CONV4, w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
     { ProfScope ps(e, 4, st); net_stage(e, st, NET_FC, w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
     { ProfScope ps(e, 5, st); net_stage(e, st, NET_HEADS, w, nullptr, legal_masks, log_policy_out, value_out, priors_out, nullptr, n); }

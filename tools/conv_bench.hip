@@ -5,15 +5,15 @@
 #include <vector>
 using namespace nnb;
 
-template <int IH, int IW, int NB, int WPS, int BRING, int ABL>
+template <int IH, int IW, int NB, int WPS, int BRING, int ARING, int ABL>
 float run(const _Float16 *in, const _Float16 *wp, const float *bias, _Float16 *out, int n, int iters) {
     constexpr size_t lds = conv_lds_bytes(IH, IW, NB);
-    auto k = conv_mid_f16_kernel<IH, IW, NB, WPS, BRING, ABL>;
+    auto k = conv_mid_f16_kernel<IH, IW, NB, WPS, BRING, ARING, false, ABL>;
     hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    for (int i = 0; i < 3; ++i) k<<<(n + NB - 1) / NB, 256, lds, 0>>>(in, wp, bias, out, nullptr, n);
+    for (int i = 0; i < 3; ++i) k<<<(n + NB - 1) / NB, 256, lds, 0>>>(in, wp, bias, out, nullptr, n, nullptr, nullptr, nullptr);
     hipEventRecord(a, 0);
-    for (int i = 0; i < iters; ++i) k<<<(n + NB - 1) / NB, 256, lds, 0>>>(in, wp, bias, out, nullptr, n);
+    for (int i = 0; i < iters; ++i) k<<<(n + NB - 1) / NB, 256, lds, 0>>>(in, wp, bias, out, nullptr, n, nullptr, nullptr, nullptr);
     hipEventRecord(b, 0); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     if (hipGetLastError() != hipSuccess) printf("launch error\n");
@@ -42,10 +42,14 @@ int main(int argc, char **argv) {
     hipMemcpy(wp, h.data(), 128 * 128 * 16 * 2, hipMemcpyHostToDevice);
     hipMemset(bias, 0, 512);
     const double f2 = 2.0 * 128 * 72 * 2048 * n, f4 = 2.0 * 128 * 90 * 2048 * n;
-#define R2(ABL) { float us = run<7, 8, 4, 2, 4, ABL>(in, wp, bias, out, n, 20); printf("conv2 ablate=%2d %8.1f us %7.1f TF\n", ABL, us, f2 / us * 1e-6); }
-#define R4(ABL) { float us = run<8, 9, 2, 2, 4, ABL>(in, wp, bias, out, n, 20); printf("conv4 ablate=%2d %8.1f us %7.1f TF\n", ABL, us, f4 / us * 1e-6); }
-    R2(0) R2(1) R2(2) R2(4) R2(8) R2(9) R2(6) R2(15)
-    R4(0) R4(1) R4(2) R4(4) R4(8) R4(9) R4(6) R4(15)
+#define R2(ABL) { float us = run<7, 8, 4, 2, 4, 8, ABL>(in, wp, bias, out, n, 20); printf("conv2 ablate=%2d %8.1f us %7.1f TF\n", ABL, us, f2 / us * 1e-6); }
+#define R4(ABL) { float us = run<8, 9, 2, 2, 4, 8, ABL>(in, wp, bias, out, n, 20); printf("conv4 ablate=%2d %8.1f us %7.1f TF\n", ABL, us, f4 / us * 1e-6); }
+    R2(0) R2(15)
+    R4(0) R4(15)
+#define V4(NB, WPS, BR, AR) { float us = run<8, 9, NB, WPS, BR, AR, 0>(in, wp, bias, out, n, 20); printf("conv4 NB=%d wps=%d bring=%d aring=%d %8.1f us %7.1f TF\n", NB, WPS, BR, AR, us, f4 / us * 1e-6); }
+    V4(2, 3, 4, 6) V4(2, 3, 2, 6) V4(2, 3, 2, 4) V4(2, 2, 4, 12) V4(2, 2, 8, 8) V4(4, 1, 8, 16) V4(4, 1, 4, 8) V4(3, 2, 4, 8)
+#define V2(NB, WPS, BR, AR) { float us = run<7, 8, NB, WPS, BR, AR, 0>(in, wp, bias, out, n, 20); printf("conv2 NB=%d wps=%d bring=%d aring=%d %8.1f us %7.1f TF\n", NB, WPS, BR, AR, us, f2 / us * 1e-6); }
+    V2(4, 2, 2, 8) V2(4, 2, 4, 4) V2(4, 2, 4, 12) V2(8, 1, 8, 16) V2(8, 1, 4, 8)
     {
         _Float16 *fa, *fw; float *part;
         hipMalloc(&fa, (size_t)n * 11520 * 2); hipMalloc(&fw, (size_t)1024 * 11520 * 2); hipMalloc(&part, (size_t)2 * n * 1024 * 4);
