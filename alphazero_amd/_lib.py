@@ -29,7 +29,7 @@ class Config(C.Structure):
 class SearchParams(C.Structure):
     _fields_ = [("mode", C.c_int32), ("evaluator", C.c_int32), ("sims", C.c_int32),
                 ("weight_set", C.c_int32), ("flags", C.c_int32), ("rng_move_index", C.c_int32),
-                ("rng_game_base", C.c_int32), ("reserved", C.c_int32),
+                ("rng_game_base", C.c_int32), ("weight_set_colour2_plus1", C.c_int32),
                 ("c_puct", C.c_double), ("dirichlet_alpha", C.c_double),
                 ("dirichlet_eps", C.c_double), ("seed", C.c_uint64)]
 

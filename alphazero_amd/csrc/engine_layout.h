@@ -48,12 +48,16 @@ struct EngineDev {
     int32_t *move_index;        // [G] move index of the current search (RNG coordinate)
     float   *root_noise;        // [G][7] Dirichlet noise mixed into the root priors (AZ)
 
-    u64     *leaf_side;         // [G][2] side boards (me, opp) of the compacted leaf batch
-    uint8_t *leaf_legal;        // [G]    legal mask of each batched leaf
-    int32_t *leaf_count;        // [2]    ring of batch sizes, indexed by step parity
-    float   *leaf_value;        // [G]    network / evaluator value per batch slot
-    float   *leaf_logp;         // [G][7] network log-policy per batch slot
-    float   *leaf_prior;        // [G][7] masked, renormalised priors per batch slot
+    // Compacted leaf batches.  There are two of them (batch b occupies slots [b*G, (b+1)*G)):
+    // when the two colours are played by different weight sets, leaves of searches whose
+    // root mover is colour 1 go to batch 0 and those of colour 2 to batch 1; otherwise only
+    // batch 0 is used.
+    u64     *leaf_side;         // [2G][2] side boards (me, opp)
+    uint8_t *leaf_legal;        // [2G]    legal mask of each batched leaf
+    int32_t *leaf_count;        // [2][2]  batch sizes, indexed by [step parity][batch]
+    float   *leaf_value;        // [2G]    network / evaluator value per batch slot
+    float   *leaf_logp;         // [2G][7] network log-policy per batch slot
+    float   *leaf_prior;        // [2G][7] masked, renormalised priors per batch slot
     int32_t *counters;          // [16]   [0] = live games after the last readout
     unsigned long long *stats64; // [8]   depth, terminal hits, leaves, sims, plies (stats_reduce_kernel)
 };
@@ -65,6 +69,7 @@ struct SearchDev {
     int32_t flags;
     int32_t rng_move_index;
     int32_t rng_game_base;
+    int32_t wset[2];            // weight set searching for colour 1 / colour 2
     double  c_puct;
     double  dirichlet_alpha;
     double  dirichlet_eps;

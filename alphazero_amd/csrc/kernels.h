@@ -25,7 +25,7 @@ void launch_search_init(hipStream_t st, const EngineDev &e, const u64 *boards, c
 void launch_dirichlet_noise(hipStream_t st, int n, u64 seed, const int32_t *game_ids, const int32_t *move_index,
                             const uint8_t *legal, double alpha, float *out);
 void launch_stats_reduce(hipStream_t st, const EngineDev &e);
-void launch_fixed_eval(hipStream_t st, const EngineDev &e, const SearchDev &p, const int32_t *count_ptr);
+void launch_fixed_eval(hipStream_t st, const EngineDev &e, const SearchDev &p, int batch, const int32_t *count_ptr);
 
 // net_kernels.hip
 struct NetWeights {            // one resident weight set, kernel layouts

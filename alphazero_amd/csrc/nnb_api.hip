@@ -40,7 +40,7 @@ int fail(int code, const char *fmt, ...) {
 constexpr size_t kAlign = 256;
 constexpr int kMaxSims = 9000;           // first_child is 16 bit: 1 + 7*sims <= 65535
 constexpr int kProfClasses = 7;
-constexpr int kProfSamples = 48;         // event pairs per class per drain
+constexpr int kProfSamples = 16;         // event pairs per class per drain
 
 struct Carver {
     unsigned char *base;
@@ -101,12 +101,12 @@ void carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std::v
     d.game_id = c.take<int32_t>(G);
     d.move_index = c.take<int32_t>(G);
     d.root_noise = c.take<float>(7 * G);
-    d.leaf_side = c.take<u64>(2 * G);
-    d.leaf_legal = c.take<uint8_t>(G);
+    d.leaf_side = c.take<u64>(4 * G);
+    d.leaf_legal = c.take<uint8_t>(2 * G);
     d.leaf_count = c.take<int32_t>(64);
-    d.leaf_value = c.take<float>(G);
-    d.leaf_logp = c.take<float>(7 * G);
-    d.leaf_prior = c.take<float>(7 * G);
+    d.leaf_value = c.take<float>(2 * G);
+    d.leaf_logp = c.take<float>(14 * G);
+    d.leaf_prior = c.take<float>(14 * G);
     d.counters = c.take<int32_t>(64);
     d.stats64 = c.take<unsigned long long>(32);
     b.act1 = c.take<float>(G * 56 * 128);
@@ -178,6 +178,7 @@ void prof_drain(nnb_engine *e) {          // call only when the stream is idle
 SearchDev to_dev(const nnb_search_params &p) {
     SearchDev s;
     s.mode = p.mode; s.evaluator = p.evaluator; s.sims = p.sims; s.flags = p.flags; s.rng_move_index = p.rng_move_index; s.rng_game_base = p.rng_game_base;
+    s.wset[0] = p.weight_set; s.wset[1] = p.weight_set_colour2_plus1 > 0 ? p.weight_set_colour2_plus1 - 1 : p.weight_set;
     s.c_puct = p.c_puct; s.dirichlet_alpha = p.dirichlet_alpha; s.dirichlet_eps = p.dirichlet_eps;
     s.seed = p.seed;
     return s;
@@ -200,11 +201,14 @@ int check_params(nnb_engine *e, const nnb_search_params *p, int n) {
         if (!(p->dirichlet_alpha >= 0.0) || !std::isfinite(p->dirichlet_alpha))
             return fail(NNB_ERR_ARG, "dirichlet_alpha must be finite and >= 0");
     }
-    if (p->evaluator == NNB_EVAL_NET) {
-        if (p->weight_set < 0 || p->weight_set >= e->cfg.n_weight_sets)
-            return fail(NNB_ERR_ARG, "weight_set %d out of range", p->weight_set);
-        if (!e->weights_loaded[p->weight_set])
-            return fail(NNB_ERR_STATE, "weight set %d has not been loaded (nnb_load_weights)", p->weight_set);
+    {
+        const int sets[2] = {p->weight_set, p->weight_set_colour2_plus1 > 0 ? p->weight_set_colour2_plus1 - 1 : p->weight_set};
+        for (int k = 0; k < 2; ++k) {
+            if (sets[k] < 0 || sets[k] >= e->cfg.n_weight_sets)
+                return fail(NNB_ERR_ARG, "weight set %d out of range [0, %d)", sets[k], e->cfg.n_weight_sets);
+            if (p->evaluator == NNB_EVAL_NET && !e->weights_loaded[sets[k]])
+                return fail(NNB_ERR_STATE, "weight set %d has not been loaded (nnb_load_weights)", sets[k]);
+        }
     }
     if (!(p->c_puct >= 0.0) || !std::isfinite(p->c_puct)) return fail(NNB_ERR_ARG, "c_puct must be finite and >= 0");
     return NNB_OK;
@@ -218,15 +222,18 @@ void net_stage(nnb_engine *e, hipStream_t st, int stage, const NetWeights &w, co
         launch_net_stage_f16(st, stage, w, e->buf, side, legal, logp, value, prior, count_ptr, n_max);
 }
 
-// Forward pass over the engine's compacted leaf batch (count on the device).
-void forward_leaves(nnb_engine *e, hipStream_t st, int weight_set, const int32_t *count_ptr, int n_max) {
+// Forward pass over one of the engine's compacted leaf batches (count on the device).
+void forward_leaves(nnb_engine *e, hipStream_t st, int weight_set, int batch, const int32_t *count_ptr, int n_max) {
     const NetWeights &w = e->weights[weight_set];
     const EngineDev &d = e->dev;
-    { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, d.leaf_side, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
-    { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, d.leaf_side, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
+    const size_t o = (size_t)batch * d.max_games;
+    const bool fused_in = e->cfg.net_precision == NNB_NET_F16;     // conv0 is part of the conv2 launch there
+    if (!fused_in) { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, d.leaf_side + 2 * o, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
+    { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, d.leaf_side + 2 * o, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
     { ProfScope ps(e, 3, st); net_stage(e, st, NET_CONV4, w, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
     { ProfScope ps(e, 4, st); net_stage(e, st, NET_FC, w, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
-    { ProfScope ps(e, 5, st); net_stage(e, st, NET_HEADS, w, nullptr, d.leaf_legal, d.leaf_logp, d.leaf_value, d.leaf_prior, count_ptr, n_max); }
+    { ProfScope ps(e, 5, st); net_stage(e, st, NET_HEADS, w, nullptr, d.leaf_legal + o, d.leaf_logp + 7 * o, d.leaf_value + o, d.leaf_prior + 7 * o, count_ptr,
+                                        n_max); }
 }
 
 // One move for every live game: S simulations, then the root readout.
@@ -248,8 +255,12 @@ int run_move(nnb_engine *e, hipStream_t st, const nnb_search_params &p, int32_t 
         for (int s = 0; s <= p.sims; ++s) {
             { ProfScope ps(e, 0, st); launch_tree_step(st, d, sd, s & 1); }
             if (s == p.sims) break;
-            if (p.evaluator == NNB_EVAL_NET) forward_leaves(e, st, p.weight_set, d.leaf_count + (s & 1), d.n_games);
-            else launch_fixed_eval(st, d, sd, d.leaf_count + (s & 1));
+            const int nbatch = sd.wset[0] == sd.wset[1] ? 1 : 2;
+            for (int b = 0; b < nbatch; ++b) {
+                const int32_t *cnt = d.leaf_count + 2 * (s & 1) + b;
+                if (p.evaluator == NNB_EVAL_NET) forward_leaves(e, st, sd.wset[b], b, cnt, d.n_games);
+                else launch_fixed_eval(st, d, sd, b, cnt);
+            }
         }
         *steps += p.sims;
     } else {

@@ -155,6 +155,10 @@ __device__ __forceinline__ void wave_mem_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// The fixed evaluators of weight set k > 0 see the position through a different hash, so a
+// two-set arena can be checked bit for bit without networks.
+__device__ __forceinline__ u64 set_mix(int wset) { return (u64)wset * 0xD6E8FEB86659FD93ULL; }
+
 __device__ __forceinline__ double fixed_eval(int evaluator, u64 me, u64 opp) {
     if (evaluator == NNB_EVAL_HASH_Q8) return c4::hash_value_q8(me, opp);
     if (evaluator == NNB_EVAL_HASH_F32) return c4::hash_value_f32(me, opp);
@@ -352,12 +356,12 @@ __device__ __forceinline__ void backup_az(Node *pool, int mypath, int len, doubl
 
 // value of a leaf for the side to move, fixed evaluators (AZ frame)
 __device__ __forceinline__ double fixed_eval_az(const SearchDev &p, u64 c1, u64 c2, int mover, uint32_t game,
-                                                uint32_t move, uint32_t sim) {
+                                                uint32_t move, uint32_t sim, u64 smix) {
     if (p.evaluator == NNB_EVAL_ROLLOUT) {
         int res = rollout(c1, c2, mover, p.seed, game, move, sim);
         return (res == 2 || res == 0) ? 0.0 : ((res == 1) == (mover == 1) ? 1.0 : -1.0);
     }
-    return fixed_eval(p.evaluator, mover == 1 ? c1 : c2, mover == 1 ? c2 : c1);
+    return fixed_eval(p.evaluator, (mover == 1 ? c1 : c2) ^ smix, mover == 1 ? c2 : c1);
 }
 
 // ---------------------------------------------------------------------------
@@ -367,7 +371,7 @@ __device__ __forceinline__ double fixed_eval_az(const SearchDev &p, u64 c1, u64 
 // ---------------------------------------------------------------------------
 __global__ void tree_init_kernel(EngineDev e, SearchDev p, int make_noise, int selfplay) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g == 0) { e.leaf_count[0] = 0; e.leaf_count[1] = 0; }
+    if (g == 0) { e.leaf_count[0] = 0; e.leaf_count[1] = 0; e.leaf_count[2] = 0; e.leaf_count[3] = 0; }
     if (g >= e.n_games) return;
     if (!e.active[g]) return;
     Node r;
@@ -399,12 +403,14 @@ constexpr int kStepGames = 16;                    // games (wavefronts) per bloc
 
 template <bool AZ>
 __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e, SearchDev p, int parity) {
-    __shared__ int s_want[kStepGames];
-    __shared__ int s_base;
+    __shared__ int s_want[kStepGames];       // 0 = no leaf, 1 + batch otherwise
+    __shared__ int s_base[2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int g = blockIdx.x * kStepGames + wv;
-    if (blockIdx.x == 0 && threadIdx.x == 0) e.leaf_count[parity ^ 1] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { e.leaf_count[2 * (parity ^ 1)] = 0; e.leaf_count[2 * (parity ^ 1) + 1] = 0; }
     const bool live = g < e.n_games && e.active[g];
+    const bool two_batches = p.wset[0] != p.wset[1];
+    int batch = 0;
     // leaf found by this wave (if any), kept in registers until the block has claimed its
     // slots in the compacted batch with ONE atomic (one per game serialised on the counter)
     bool want = false;
@@ -419,6 +425,7 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
     n_nodes = e.n_nodes[g];
     const int player = e.root_player[g];
     const u64 r1 = e.root_boards[2 * g], r2 = e.root_boards[2 * g + 1];
+    batch = two_batches ? player - 1 : 0;      // every leaf of a search is judged by the root mover's network
 
     int pend = e.pending[g];
     if (pend >= 0) {
@@ -481,19 +488,19 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
     }
     }   // live
 
-    if (lane == 0) s_want[wv] = want ? 1 : 0;
+    if (lane == 0) s_want[wv] = want ? 1 + batch : 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 2) {
         int total = 0;
-        for (int k = 0; k < kStepGames; ++k) total += s_want[k];
-        s_base = total ? atomicAdd(&e.leaf_count[parity], total) : 0;
+        for (int k = 0; k < kStepGames; ++k) total += s_want[k] == 1 + (int)threadIdx.x;
+        s_base[threadIdx.x] = total ? atomicAdd(&e.leaf_count[2 * parity + threadIdx.x], total) : 0;
     }
     __syncthreads();
     if (!live) return;
     int pend_out = -1;
     if (want) {
-        int slot = s_base;
-        for (int k = 0; k < wv; ++k) slot += s_want[k];
+        int slot = batch * e.max_games + s_base[batch];
+        for (int k = 0; k < wv; ++k) slot += s_want[k] == 1 + batch;
         if (lane == 0) {
             e.leaf_side[2 * slot] = leaf_me;
             e.leaf_side[2 * slot + 1] = leaf_opp;
@@ -540,6 +547,7 @@ __global__ __launch_bounds__(64) void tree_fused_kernel(EngineDev e, SearchDev p
     const int player = e.root_player[g];
     const u64 r1 = e.root_boards[2 * g], r2 = e.root_boards[2 * g + 1];
     const uint32_t game = (uint32_t)e.game_id[g], move = (uint32_t)e.move_index[g];
+    const u64 smix = set_mix(p.wset[player - 1]);
     int n_nodes = 1, depth_sum = 0, term_hits = 0, leaves = 0;
     for (int s = 0; s < p.sims; ++s) {
         int mypath;
@@ -553,11 +561,11 @@ __global__ __launch_bounds__(64) void tree_fused_kernel(EngineDev e, SearchDev p
                 ++term_hits;
             } else {
                 const u64 me = d.mover == 1 ? d.c1 : d.c2, opp = d.mover == 1 ? d.c2 : d.c1;
-                float pr = lane < 7 ? fixed_prior(p.evaluator, me, opp, legal, lane) : 0.0f;
+                float pr = lane < 7 ? fixed_prior(p.evaluator, me ^ smix, opp, legal, lane) : 0.0f;
                 if (d.len == 1 && p.dirichlet_eps > 0.0 && lane < 7)
                     pr = (float)((1.0 - p.dirichlet_eps) * (double)pr + p.dirichlet_eps * (double)e.root_noise[7 * g + lane]);
                 n_nodes += expand_az(pool, prior, d.node, n_nodes, legal, pr, lane);
-                v = fixed_eval_az(p, d.c1, d.c2, d.mover, game, move, (uint32_t)s);
+                v = fixed_eval_az(p, d.c1, d.c2, d.mover, game, move, (uint32_t)s, smix);
                 ++leaves;
             }
             backup_az(pool, mypath, d.len, v, lane);
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(64) void tree_fused_kernel(EngineDev e, SearchDev p
                     int res = rollout(d.c1, d.c2, player, p.seed, game, move, (uint32_t)s);
                     v = res == 1 ? -1.0 : (res == -1 ? 1.0 : 0.0);
                 } else {
-                    v = fixed_eval(p.evaluator, player == 1 ? d.c1 : d.c2, player == 1 ? d.c2 : d.c1);
+                    v = fixed_eval(p.evaluator, (player == 1 ? d.c1 : d.c2) ^ smix, player == 1 ? d.c2 : d.c1);
                 }
                 ++leaves;
             }
@@ -712,10 +720,11 @@ __global__ void stats_reduce_kernel(EngineDev e) {
 
 // Fixed evaluators over the compacted leaf batch: fills the value buffer exactly as the
 // network's heads kernel would, so the lock-step path can be run without weights.
-__global__ void fixed_eval_kernel(EngineDev e, SearchDev p, const int32_t *__restrict__ count_ptr) {
+__global__ void fixed_eval_kernel(EngineDev e, SearchDev p, int batch, const int32_t *__restrict__ count_ptr) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= *count_ptr) return;
-    const u64 me = e.leaf_side[2 * i], opp = e.leaf_side[2 * i + 1];
+    i += batch * e.max_games;
+    const u64 me = e.leaf_side[2 * i] ^ set_mix(p.wset[batch]), opp = e.leaf_side[2 * i + 1];
     e.leaf_value[i] = (float)fixed_eval(p.evaluator, me, opp);
     if (p.mode == NNB_MODE_AZ) {
         const unsigned legal = e.leaf_legal[i];
@@ -793,8 +802,8 @@ void launch_search_init(hipStream_t st, const EngineDev &e, const u64 *boards, c
     search_init_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, boards, players, game_base, root_noise);
 }
 
-void launch_fixed_eval(hipStream_t st, const EngineDev &e, const SearchDev &p, const int32_t *count_ptr) {
-    fixed_eval_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, p, count_ptr);
+void launch_fixed_eval(hipStream_t st, const EngineDev &e, const SearchDev &p, int batch, const int32_t *count_ptr) {
+    fixed_eval_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, p, batch, count_ptr);
 }
 
 void launch_stats_reduce(hipStream_t st, const EngineDev &e) {

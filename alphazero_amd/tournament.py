@@ -7,13 +7,22 @@ tournament/results/tournament_results.json.  Agents are asked for a move with th
 object (what AlphaZeroAgent.select_move and MinimaxAgent.select_move both take) and may
 return either a column or a (column, distribution) pair.  Tallies are keyed by class name,
 with an index appended when two agents share a class.
+
+Two engine-backed AlphaZeroAgents with the same search settings do not take turns on the
+host at all: `arena` plays every game of the tournament concurrently on one engine that
+holds both networks, each search's leaves batched with the other games' leaves that the
+same network judges (`run_tournament` takes that route by itself).
 """
 from __future__ import annotations
 
 import json
 import os
 
+import numpy as np
+
 from .game import AI_PIECE, PLAYER_PIECE, ConnectFourGame
+
+ARENA_CONCURRENT_GAMES = 4096    # games per engine call; longer tournaments run in rounds
 
 
 def _names(agents):
@@ -47,13 +56,75 @@ def play_match(agents, names, game, starter: int):
     return "draws"
 
 
-def run_tournament(agents, num_games=100, results_dir=os.path.join("tournament", "results")):
+def arena_capable(agents) -> bool:
+    """True when the pair can be played batched on one engine: two AlphaZeroAgents with the
+    same simulation count, exploration constant and evaluator kind."""
+    from .agent import AlphaZeroAgent
+    if len(agents) != 2 or not all(isinstance(a, AlphaZeroAgent) for a in agents):
+        return False
+    a, b = agents
+    return (a.num_simulations == b.num_simulations and a.c_puct == b.c_puct and a.evaluator == b.evaluator
+            and a.num_simulations >= 2)
+
+
+def arena(agents, num_games: int, engine=None, first_game_id: int = 0):
+    """Plays `num_games` games between two AlphaZeroAgents on the GPU, all games at once.
+
+    agents[0] plays colour 1 and agents[1] colour 2; game i is started by agents[i % 2]
+    (run_tournament.py:17-19).  Returns (wins of agents[0], wins of agents[1], draws, records)
+    with `records` the engine's trajectory records (engine.TRAJECTORY_DTYPE).  A game that
+    ends with a full board, or in which the mover has no move, is a draw
+    (run_tournament.py:30-35).
+    """
+    from .engine import Engine, trajectories_to_numpy
+    if not arena_capable(agents):
+        raise ValueError("arena needs two AlphaZeroAgents with equal num_simulations, c_puct and evaluator")
+    a, b = agents
+    for ag in agents:
+        if ag.load_model_flag and not ag.model_loaded:
+            ag.load_model()
+    n_round = min(int(num_games), ARENA_CONCURRENT_GAMES)
+    own = engine is None
+    if own:
+        engine = Engine(max_games=max(n_round, 1), max_sims=a.num_simulations, n_weight_sets=2)
+    try:
+        if a.evaluator == "net":
+            engine.load_state_dict(a.model.state_dict(), weight_set=0)
+            engine.load_state_dict(b.model.state_dict(), weight_set=1)
+        params = engine.params(a.num_simulations, a.c_puct, evaluator=a.evaluator, mode="compat", weight_set=0,
+                               weight_set_colour2=1)
+        recs = []
+        done = 0
+        while done < num_games:
+            n = min(n_round, num_games - done)
+            starters = (1 + (np.arange(done, done + n) % 2)).astype(np.int8)
+            traj, _stats = engine.selfplay_round(n, params, first_game_id=first_game_id + done,
+                                                 start_boards=np.zeros((n, 2), dtype=np.uint64), start_players=starters)
+            recs.append(trajectories_to_numpy(traj))
+            done += n
+    finally:
+        if own:
+            engine.close()
+    records = np.concatenate(recs) if recs else np.zeros(0, dtype=np.uint8)
+    res = records["result"] if len(records) else np.zeros(0, dtype=np.int32)
+    wins_a, wins_b = int((res == 1).sum()), int((res == -1).sum())
+    return wins_a, wins_b, int(len(res) - wins_a - wins_b), records
+
+
+def run_tournament(agents, num_games=100, results_dir=os.path.join("tournament", "results"), batched=None):
+    """run_tournament.py:12-42.  batched=None picks the engine arena when the pair allows it."""
     names = _names(agents)
     results = {n: 0 for n in names}
     results["draws"] = 0
-    game = ConnectFourGame()
-    for i in range(num_games):
-        results[play_match(agents, names, game, i % 2)] += 1
+    if batched is None:
+        batched = arena_capable(agents)
+    if batched:
+        wa, wb, dr, _ = arena(agents, num_games)
+        results[names[0]], results[names[1]], results["draws"] = wa, wb, dr
+    else:
+        game = ConnectFourGame()
+        for i in range(num_games):
+            results[play_match(agents, names, game, i % 2)] += 1
     os.makedirs(results_dir, exist_ok=True)
     path = os.path.join(results_dir, "tournament_results.json")
     with open(path, "w") as f:
@@ -62,4 +133,4 @@ def run_tournament(agents, num_games=100, results_dir=os.path.join("tournament",
     return results
 
 
-__all__ = ["run_tournament", "play_match"]
+__all__ = ["run_tournament", "play_match", "arena", "arena_capable"]

@@ -93,11 +93,12 @@ typedef struct nnb_search_params {
     int32_t mode;        /* nnb_mode                                               */
     int32_t evaluator;   /* nnb_evaluator                                          */
     int32_t sims;        /* simulations per move (agent.num_simulations)           */
-    int32_t weight_set;  /* which resident weight set NET uses                     */
+    int32_t weight_set;  /* resident weight set of the searcher (of colour 1 in an arena)  */
     int32_t flags;       /* NNB_FLAG_* bits                                        */
     int32_t rng_move_index; /* nnb_search only: move-index coordinate of the RNG   */
     int32_t rng_game_base;  /* nnb_search only: root i draws as game rng_game_base+i */
-    int32_t reserved;
+    int32_t weight_set_colour2_plus1; /* 0: searches for colour 2 use weight_set too; k > 0: they use
+                                         weight set k-1 (two-network arena, run_tournament.py:12-42) */
     double  c_puct;      /* exploration constant (agent.c_puct, default 1.4)       */
     double  dirichlet_alpha;   /* AZ only; 0 disables root noise                   */
     double  dirichlet_eps;     /* AZ only; mixing weight of the noise              */
