@@ -176,12 +176,12 @@ def main():
         traffic, traffic_src = None, None
         try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes (collected offline)
             import glob
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-            if files:
-                tj = json.load(open(files[-1]))
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+                tj = json.load(open(path))
                 if tj.get("dtype", "f32") == args.precision and G == GAMES_PER_GPU and args.sims == SIMS:
                     traffic = tj["kernels"][dom]["hbm_bytes"]
-                    traffic_src = os.path.relpath(files[-1], ROOT)
+                    traffic_src = os.path.relpath(path, ROOT)
+                    break
         except Exception:
             traffic = None
         plies_per_game = job["plies"] / max(games, 1)

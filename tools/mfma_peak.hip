@@ -1,0 +1,47 @@
+// Practical MFMA ceiling of the box: every SIMD issues v_mfma_f32_32x32x16_f16 back to back from
+// registers (no memory traffic).  Prints achieved TFLOP/s and the shader clock under that load
+// (s_memtime ticks per wall-clock tick).   hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o tools/mfma_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void spin(int iters, float *out, unsigned long long *clk) {
+    half8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(0.5f + i); }
+    float16v c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    unsigned long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c3, 0, 0, 0);
+    }
+    unsigned long long t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    float s = 0;
+    for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
+}
+
+int main() {
+    const int blocks = 256 * 2, iters = 20000;      // 2 blocks of 4 waves per CU = 2 waves per SIMD
+    float *out; unsigned long long *clk;
+    hipMalloc(&out, blocks * 256 * sizeof(float));
+    hipMalloc(&clk, 16);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        spin<<<blocks, 256>>>(iters, out, clk);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+        double flop = (double)blocks * 4 * iters * 4 * 32768.0;
+        printf("rep %d: %.3f ms  %.1f TFLOP/s  shader ticks %llu  wall ticks (100 MHz) %llu -> %.0f MHz\n", rep, ms,
+               flop / (ms * 1e-3) / 1e12, h[0], h[1], (double)h[0] / (double)h[1] * 100.0);
+    }
+    return 0;
+}
