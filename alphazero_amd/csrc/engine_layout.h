@@ -43,7 +43,8 @@ struct EngineDev {
     int32_t *path_len;          // [G]
     uint16_t *path;             // [G][kPathSlots] node indices root -> leaf of the pending leaf
     int32_t *ply;               // [G] plies played (self-play)
-    int32_t *game_stats;        // [G][4]: depth_sum, terminal_hits, net_leaves, sims
+    int32_t *game_stats;        // [G][8]: depth_sum, terminal_hits, net_leaves, sims, plies of retired games
+    int32_t *traj_index;        // [G] which trajectory record (game of the round) the slot is playing
     int32_t *game_id;           // [G] global game index (RNG coordinate)
     int32_t *move_index;        // [G] move index of the current search (RNG coordinate)
     float   *root_noise;        // [G][7] Dirichlet noise mixed into the root priors (AZ)
@@ -61,6 +62,17 @@ struct EngineDev {
     int32_t *counters;          // [16]   [0] = live games after the last readout
     unsigned long long *stats64; // [8]   depth, terminal hits, leaves, sims, plies (stats_reduce_kernel)
 };
+
+// A self-play round: `total_games` games are played on n_games <= total_games slots; a slot whose
+// game ends takes the next unplayed game, n_games + counters[kRefills]++, until none is left.
+struct RoundDev {
+    const u64 *start_boards;    // [total_games][2] or null (empty boards)
+    const int8_t *start_players; // [total_games] or null (colour 1 starts)
+    nnb_trajectory *traj;       // [total_games]
+    int32_t total_games;
+    int32_t first_game_id;
+};
+constexpr int kRefills = 16;    // index into EngineDev::counters; entries 0..15 are cleared every move
 
 struct SearchDev {
     int32_t mode;

@@ -17,9 +17,8 @@ void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, in
 hipError_t prepare_tree_fused(size_t lds_bytes);
 void launch_tree_fused(hipStream_t st, const EngineDev &e, const SearchDev &p, size_t lds_bytes);
 void launch_readout(hipStream_t st, const EngineDev &e, const SearchDev &p, int32_t *visits_out,
-                    int8_t *action_out, double *root_value_out, nnb_trajectory *traj, int selfplay);
-void launch_selfplay_init(hipStream_t st, const EngineDev &e, const u64 *start_boards,
-                          const int8_t *start_players, nnb_trajectory *traj, int first_game_id);
+                    int8_t *action_out, double *root_value_out, const RoundDev *round);
+void launch_selfplay_init(hipStream_t st, const EngineDev &e, const RoundDev &round);
 void launch_search_init(hipStream_t st, const EngineDev &e, const u64 *boards, const int8_t *players,
                         int game_base, const float *root_noise);
 void launch_dirichlet_noise(hipStream_t st, int n, u64 seed, const int32_t *game_ids, const int32_t *move_index,

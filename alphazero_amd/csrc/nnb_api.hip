@@ -97,7 +97,8 @@ void carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std::v
     d.path_len = c.take<int32_t>(G);
     d.path = c.take<uint16_t>(G * kPathSlots);
     d.ply = c.take<int32_t>(G);
-    d.game_stats = c.take<int32_t>(4 * G);
+    d.game_stats = c.take<int32_t>(8 * G);
+    d.traj_index = c.take<int32_t>(G);
     d.game_id = c.take<int32_t>(G);
     d.move_index = c.take<int32_t>(G);
     d.root_noise = c.take<float>(7 * G);
@@ -238,8 +239,9 @@ void forward_leaves(nnb_engine *e, hipStream_t st, int weight_set, int batch, co
 
 // One move for every live game: S simulations, then the root readout.
 int run_move(nnb_engine *e, hipStream_t st, const nnb_search_params &p, int32_t *visits_out,
-             int8_t *action_out, double *root_value_out, nnb_trajectory *traj, int selfplay,
+             int8_t *action_out, double *root_value_out, const RoundDev *round,
              bool noise_given, long long *steps) {
+    const int selfplay = round != nullptr;
     SearchDev sd = to_dev(p);
     const EngineDev &d = e->dev;
     e->prof_stride = p.sims / kProfSamples + 1;
@@ -276,7 +278,7 @@ int run_move(nnb_engine *e, hipStream_t st, const nnb_search_params &p, int32_t 
         { ProfScope ps(e, 0, st); launch_tree_fused(st, d, sd, lds); }
         *steps += 1;
     }
-    { ProfScope ps(e, 6, st); launch_readout(st, d, sd, visits_out, action_out, root_value_out, traj, selfplay); }
+    { ProfScope ps(e, 6, st); launch_readout(st, d, sd, visits_out, action_out, root_value_out, round); }
     HIP_TRY(hipGetLastError());
     return NNB_OK;
 }
@@ -461,7 +463,7 @@ int nnb_search(nnb_engine *e, void *stream, const nnb_search_params *params, int
     launch_search_init(st, e->dev, reinterpret_cast<const u64 *>(root_colour_boards), root_players,
                        params->rng_game_base, root_noise);
     long long steps = 0;
-    rc = run_move(e, st, *params, visits_out, action_out, root_value_out, nullptr, 0, root_noise != nullptr, &steps);
+    rc = run_move(e, st, *params, visits_out, action_out, root_value_out, nullptr, root_noise != nullptr, &steps);
     if (rc) return rc;
     return collect_stats(e, st, stats_out, steps, 1, n);
 }
@@ -469,23 +471,28 @@ int nnb_search(nnb_engine *e, void *stream, const nnb_search_params *params, int
 int nnb_selfplay_round(nnb_engine *e, void *stream, const nnb_search_params *params, int32_t n_games,
                        int32_t first_game_id, const uint64_t *start_colour_boards, const int8_t *start_players,
                        nnb_trajectory *trajectories_out, nnb_round_stats *stats_out) {
-    int rc = check_params(e, params, n_games);
+    if (!e) return fail(NNB_ERR_ARG, "engine is null");
+    if (n_games < 0) return fail(NNB_ERR_ARG, "n_games < 0");
+    const int slots = n_games < e->cfg.max_games ? n_games : e->cfg.max_games;
+    int rc = check_params(e, params, slots);
     if (rc) return rc;
     if (!trajectories_out) return fail(NNB_ERR_ARG, "trajectories_out is null");
     if ((start_colour_boards == nullptr) != (start_players == nullptr))
         return fail(NNB_ERR_ARG, "start boards and start players must be given together");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    e->dev.n_games = n_games;
-    HIP_TRY(hipMemsetAsync(e->dev.counters, 0, 16 * sizeof(int32_t), st));
-    launch_selfplay_init(st, e->dev, reinterpret_cast<const u64 *>(start_colour_boards), start_players,
-                         trajectories_out, first_game_id);
+    e->dev.n_games = slots;
+    const RoundDev round = {reinterpret_cast<const u64 *>(start_colour_boards), start_players, trajectories_out, n_games,
+                            first_game_id};
+    HIP_TRY(hipMemsetAsync(e->dev.counters, 0, 32 * sizeof(int32_t), st));      // live count and refill count
+    launch_selfplay_init(st, e->dev, round);
     HIP_TRY(hipMemcpyAsync(e->host_counters, e->dev.counters, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     long long steps = 0, rounds = 0;
+    const long long max_rounds = ((long long)n_games / (slots > 0 ? slots : 1) + 2) * (kMaxPlies + 1);
     int live = e->host_counters[0];
-    while (live > 0 && rounds < kMaxPlies + 1) {
+    while (live > 0 && rounds < max_rounds) {
         HIP_TRY(hipMemsetAsync(e->dev.counters, 0, 16 * sizeof(int32_t), st));
-        rc = run_move(e, st, *params, nullptr, nullptr, nullptr, trajectories_out, 1, false, &steps);
+        rc = run_move(e, st, *params, nullptr, nullptr, nullptr, &round, false, &steps);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(e->host_counters, e->dev.counters, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

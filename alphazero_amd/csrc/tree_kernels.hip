@@ -514,7 +514,7 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
         e.sims_done[g] = sims_done;
         e.n_nodes[g] = n_nodes;
         e.pending[g] = pend_out;
-        int32_t *st = e.game_stats + 4 * g;
+        int32_t *st = e.game_stats + 8 * g;
         st[0] += depth_sum; st[1] += term_hits; st[2] += want ? 1 : 0;
     }
 }
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(64) void tree_fused_kernel(EngineDev e, SearchDev p
         e.sims_done[g] = p.sims;
         e.n_nodes[g] = n_nodes;
         e.pending[g] = -1;
-        int32_t *st = e.game_stats + 4 * g;
+        int32_t *st = e.game_stats + 8 * g;
         st[0] += depth_sum; st[1] += term_hits; st[2] += leaves;
     }
 }
@@ -610,9 +610,31 @@ __global__ __launch_bounds__(64) void tree_fused_kernel(EngineDev e, SearchDev p
 // appended to the game's trajectory and finished games are retired
 // (train_alpha_zero.py:41-48).  One thread per game.
 // ---------------------------------------------------------------------------
+// Puts game j of the round into slot g; returns false when that game starts from a finished
+// position (its record is then complete and the slot is still free).
+__device__ bool seat_game(const EngineDev &e, const RoundDev &r, int g, int j) {
+    u64 b1 = r.start_boards ? r.start_boards[2 * j] : 0, b2 = r.start_boards ? r.start_boards[2 * j + 1] : 0;
+    int player = r.start_players ? r.start_players[j] : 1;
+    nnb_trajectory *t = r.traj + j;
+    t->length = 0; t->result = 2; t->game_id = r.first_game_id + j; t->reserved = 0;
+    t->final_boards[0] = b1; t->final_boards[1] = b2;
+    uint4 *z = reinterpret_cast<uint4 *>(t->plies);           // plies past `length` read as zero
+    for (int k = 0; k < (int)(sizeof(t->plies) / (sizeof(uint4))); ++k) z[k] = make_uint4(0, 0, 0, 0);
+    if (c4::is_terminal(b1, b2)) {
+        t->result = c4::result(b1, b2);
+        return false;
+    }
+    e.root_boards[2 * g] = b1; e.root_boards[2 * g + 1] = b2;
+    e.root_player[g] = (int8_t)player;
+    e.ply[g] = 0;
+    e.game_id[g] = r.first_game_id + j;
+    e.traj_index[g] = j;
+    return true;
+}
+
 __global__ void readout_kernel(EngineDev e, SearchDev p, int32_t *__restrict__ visits_out,
                                int8_t *__restrict__ action_out, double *__restrict__ root_value_out,
-                               nnb_trajectory *__restrict__ traj, int selfplay) {
+                               RoundDev round, int selfplay) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= e.n_games) return;
     if (!e.active[g]) return;
@@ -629,13 +651,13 @@ __global__ void readout_kernel(EngineDev e, SearchDev p, int32_t *__restrict__ v
         for (int c = 0; c < 7; ++c) visits_out[7 * g + c] = vis[c];
     if (action_out) action_out[g] = (int8_t)best_a;
     if (root_value_out) root_value_out[g] = root.value;
-    e.game_stats[4 * g + 3] += e.sims_done[g];
+    e.game_stats[8 * g + 3] += e.sims_done[g];
     if (!selfplay) return;
 
     u64 b1 = e.root_boards[2 * g], b2 = e.root_boards[2 * g + 1];
     int player = e.root_player[g];
     int ply = e.ply[g];
-    nnb_trajectory *t = traj + g;
+    nnb_trajectory *t = round.traj + e.traj_index[g];
     bool done = best_a < 0 || ply >= kMaxPlies;
     if (!done) {
         nnb_ply *rec = &t->plies[ply];
@@ -653,36 +675,40 @@ __global__ void readout_kernel(EngineDev e, SearchDev p, int32_t *__restrict__ v
         done = c4::is_terminal(b1, b2);                       // train_alpha_zero.py:41
     }
     if (done) {
-        e.active[g] = 0;
         t->length = ply;
         t->result = c4::result(b1, b2);                       // train_alpha_zero.py:48
         t->final_boards[0] = b1; t->final_boards[1] = b2;
-    } else {
-        atomicAdd(&e.counters[0], 1);
+        e.game_stats[8 * g + 4] += ply;
+        e.ply[g] = 0;
+        // the slot takes the next unplayed game of the round, if any
+        bool seated = false;
+        while (!seated) {
+            int j = e.n_games + atomicAdd(&e.counters[kRefills], 1);
+            if (j >= round.total_games) break;
+            seated = seat_game(e, round, g, j);
+        }
+        if (!seated) e.active[g] = 0;
+        done = !seated;
     }
+    if (!done) atomicAdd(&e.counters[0], 1);
 }
 
-// Self-play set-up: empty boards (ConnectFourGame.reset, connect_four_game.py:30-36)
-// or caller-supplied start positions; games that start terminal are retired at once.
-__global__ void selfplay_init_kernel(EngineDev e, const u64 *__restrict__ start_boards,
-                                     const int8_t *__restrict__ start_players,
-                                     nnb_trajectory *__restrict__ traj, int first_game_id) {
+// Self-play set-up: slot g starts with game g of the round - the empty board
+// (ConnectFourGame.reset, connect_four_game.py:30-36) or the caller's start position.  A game
+// that starts from a finished position is retired at once and the slot takes another one.
+__global__ void selfplay_init_kernel(EngineDev e, RoundDev round) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= e.n_games) return;
-    u64 b1 = start_boards ? start_boards[2 * g] : 0, b2 = start_boards ? start_boards[2 * g + 1] : 0;
-    int player = start_players ? start_players[g] : 1;
-    e.root_boards[2 * g] = b1; e.root_boards[2 * g + 1] = b2;
-    e.root_player[g] = (int8_t)player;
+    for (int k = 0; k < 8; ++k) e.game_stats[8 * g + k] = 0;
     e.ply[g] = 0;
-    e.game_id[g] = first_game_id + g;
-    for (int k = 0; k < 4; ++k) e.game_stats[4 * g + k] = 0;
-    nnb_trajectory *t = traj + g;
-    t->length = 0; t->result = 2; t->game_id = first_game_id + g; t->reserved = 0;
-    t->final_boards[0] = b1; t->final_boards[1] = b2;
-    bool term = c4::is_terminal(b1, b2);
-    e.active[g] = term ? 0 : 1;
-    if (term) t->result = c4::result(b1, b2);
-    else atomicAdd(&e.counters[0], 1);
+    bool seated = seat_game(e, round, g, g);
+    while (!seated) {
+        int j = e.n_games + atomicAdd(&e.counters[kRefills], 1);
+        if (j >= round.total_games) break;
+        seated = seat_game(e, round, g, j);
+    }
+    e.active[g] = seated ? 1 : 0;
+    if (seated) atomicAdd(&e.counters[0], 1);
 }
 
 // Search-only set-up: caller-supplied roots, every root searched.
@@ -698,7 +724,7 @@ __global__ void search_init_kernel(EngineDev e, const u64 *__restrict__ boards,
     e.game_id[g] = game_base + g;
     if (root_noise)
         for (int c = 0; c < 7; ++c) e.root_noise[7 * g + c] = root_noise[7 * g + c];
-    for (int k = 0; k < 4; ++k) e.game_stats[4 * g + k] = 0;
+    for (int k = 0; k < 8; ++k) e.game_stats[8 * g + k] = 0;
 }
 
 // Sums the per-game statistics into counters[8..11] (depth, terminal hits, leaves, sims)
@@ -707,8 +733,8 @@ __global__ void stats_reduce_kernel(EngineDev e) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     long long v[5] = {0, 0, 0, 0, 0};
     if (g < e.n_games) {
-        for (int k = 0; k < 4; ++k) v[k] = e.game_stats[4 * g + k];
-        v[4] = e.ply[g];
+        for (int k = 0; k < 4; ++k) v[k] = e.game_stats[8 * g + k];
+        v[4] = e.game_stats[8 * g + 4] + e.ply[g];
     }
     for (int k = 0; k < 5; ++k) {
         long long x = v[k];
@@ -786,15 +812,14 @@ void launch_dirichlet_noise(hipStream_t st, int n, u64 seed, const int32_t *game
 }
 
 void launch_readout(hipStream_t st, const EngineDev &e, const SearchDev &p, int32_t *visits_out,
-                    int8_t *action_out, double *root_value_out, nnb_trajectory *traj, int selfplay) {
-    readout_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, p, visits_out, action_out, root_value_out, traj,
-                                                         selfplay);
+                    int8_t *action_out, double *root_value_out, const RoundDev *round) {
+    RoundDev none = {nullptr, nullptr, nullptr, 0, 0};
+    readout_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, p, visits_out, action_out, root_value_out,
+                                                         round ? *round : none, round != nullptr);
 }
 
-void launch_selfplay_init(hipStream_t st, const EngineDev &e, const u64 *start_boards,
-                          const int8_t *start_players, nnb_trajectory *traj, int first_game_id) {
-    selfplay_init_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, start_boards, start_players, traj,
-                                                               first_game_id);
+void launch_selfplay_init(hipStream_t st, const EngineDev &e, const RoundDev &round) {
+    selfplay_init_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, round);
 }
 
 void launch_search_init(hipStream_t st, const EngineDev &e, const u64 *boards, const int8_t *players,

@@ -20,7 +20,7 @@ from .game import bits_to_board
 
 logger = logging.getLogger(__name__)
 
-MAX_CONCURRENT_GAMES = 4096      # games per engine call; larger requests run in rounds
+MAX_CONCURRENT_GAMES = 4096      # games in flight per engine; a longer round refills slots as games end
 
 
 def shard_range(num_games: int, rank: int, world: int) -> Tuple[int, int]:
@@ -47,21 +47,19 @@ def play_games(agent, num_games: int, first_game_id: int = 0, start_boards=None,
     """Plays `num_games` games on the agent's engine; returns (records, stats) where records is a
     structured numpy array (engine.TRAJECTORY_DTYPE) and stats sums the engine's round statistics."""
     from .engine import trajectories_to_numpy
-    recs, totals = [], {}
-    done = 0
-    while done < num_games:
-        n = min(MAX_CONCURRENT_GAMES, num_games - done)
-        eng = agent.engine(n)
-        params = eng.params(agent.num_simulations, agent.c_puct, evaluator=agent.evaluator, mode="compat")
-        sb = None if start_boards is None else start_boards[done:done + n]
-        sp = None if start_players is None else start_players[done:done + n]
-        traj, stats = eng.selfplay_round(n, params, first_game_id=first_game_id + done, start_boards=sb,
-                                         start_players=sp)
-        recs.append(trajectories_to_numpy(traj))
-        for k, v in stats.items():
-            totals[k] = totals.get(k, 0) + v
-        done += n
-    return np.concatenate(recs), totals
+    num_games = int(num_games)
+    if num_games <= 0:
+        return np.zeros(0, dtype=_trajectory_dtype()), {}
+    eng = agent.engine(min(num_games, MAX_CONCURRENT_GAMES))
+    params = eng.params(agent.num_simulations, agent.c_puct, evaluator=agent.evaluator, mode="compat")
+    traj, stats = eng.selfplay_round(num_games, params, first_game_id=first_game_id, start_boards=start_boards,
+                                     start_players=start_players)
+    return trajectories_to_numpy(traj), dict(stats)
+
+
+def _trajectory_dtype():
+    from .engine import TRAJECTORY_DTYPE
+    return TRAJECTORY_DTYPE
 
 
 def _planes(b1: int, b2: int, me: int) -> np.ndarray:

@@ -22,7 +22,7 @@ import numpy as np
 
 from .game import AI_PIECE, PLAYER_PIECE, ConnectFourGame
 
-ARENA_CONCURRENT_GAMES = 4096    # games per engine call; longer tournaments run in rounds
+ARENA_CONCURRENT_GAMES = 4096    # games in flight; a longer tournament refills slots as games end
 
 
 def _names(agents):
@@ -76,7 +76,7 @@ def arena(agents, num_games: int, engine=None, first_game_id: int = 0):
     ends with a full board, or in which the mover has no move, is a draw
     (run_tournament.py:30-35).
     """
-    from .engine import Engine, trajectories_to_numpy
+    from .engine import TRAJECTORY_DTYPE, Engine, trajectories_to_numpy
     if not arena_capable(agents):
         raise ValueError("arena needs two AlphaZeroAgents with equal num_simulations, c_puct and evaluator")
     a, b = agents
@@ -93,20 +93,17 @@ def arena(agents, num_games: int, engine=None, first_game_id: int = 0):
             engine.load_state_dict(b.model.state_dict(), weight_set=1)
         params = engine.params(a.num_simulations, a.c_puct, evaluator=a.evaluator, mode="compat", weight_set=0,
                                weight_set_colour2=1)
-        recs = []
-        done = 0
-        while done < num_games:
-            n = min(n_round, num_games - done)
-            starters = (1 + (np.arange(done, done + n) % 2)).astype(np.int8)
-            traj, _stats = engine.selfplay_round(n, params, first_game_id=first_game_id + done,
+        n = int(num_games)
+        records = np.zeros(0, dtype=TRAJECTORY_DTYPE)
+        if n > 0:
+            starters = (1 + (np.arange(n) % 2)).astype(np.int8)
+            traj, _stats = engine.selfplay_round(n, params, first_game_id=first_game_id,
                                                  start_boards=np.zeros((n, 2), dtype=np.uint64), start_players=starters)
-            recs.append(trajectories_to_numpy(traj))
-            done += n
+            records = trajectories_to_numpy(traj)
     finally:
         if own:
             engine.close()
-    records = np.concatenate(recs) if recs else np.zeros(0, dtype=np.uint8)
-    res = records["result"] if len(records) else np.zeros(0, dtype=np.int32)
+    res = records["result"]
     wins_a, wins_b = int((res == 1).sum()), int((res == -1).sum())
     return wins_a, wins_b, int(len(res) - wins_a - wins_b), records
 

@@ -217,11 +217,16 @@ int nnb_search(nnb_engine *engine, void *stream, const nnb_search_params *params
                const float *root_noise, int32_t *visits_out, int8_t *action_out,
                double *root_value_out, nnb_round_stats *stats_out);
 
-/* Plays n_games <= max_games self-play games to the end in lock step, the same
- * searcher on both sides (self_play, train_alpha_zero.py:33-55).  Game i starts from
- * the empty board, or from start_colour_boards[i]/start_players[i] when given, and
- * is recorded in trajectories_out[i] (device memory, n_games records) with
- * game_id = first_game_id + i.  stats_out is a host pointer.  Synchronous. */
+/* Plays n_games self-play games to the end, the same searcher on both sides (self_play,
+ * train_alpha_zero.py:33-55), or one weight set per colour (run_tournament.py:12-42).
+ * At most max_games games are in flight, all advancing in lock step; when n_games is
+ * larger, a game that ends hands its slot to the next unplayed game, so the leaf batch
+ * stays full until the round runs out of games.  Game i starts from the empty board, or
+ * from start_colour_boards[i]/start_players[i] when given, and is recorded in
+ * trajectories_out[i] (device memory, n_games records, plies past `length` zeroed) with
+ * game_id = first_game_id + i;
+ * what a game plays depends on its id and start position only, not on the slot or the
+ * moment it was seated.  stats_out is a host pointer.  Synchronous. */
 int nnb_selfplay_round(nnb_engine *engine, void *stream, const nnb_search_params *params,
                        int32_t n_games, int32_t first_game_id,
                        const uint64_t *start_colour_boards, const int8_t *start_players,

@@ -1,0 +1,104 @@
+"""Self-play rounds longer than the engine's slot count: a slot whose game ends takes the next
+unplayed game (the batched form of the sequential game loop in train_alpha_zero.py:37-55).
+What a game plays must depend on its id and start position only."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import c_oracle as co
+    from oracle import ref_port as rp
+    return co, rp
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (torch.cuda.is_available() is False)")
+    return torch
+
+
+def _positions(co, n, seed, max_plies):
+    rng = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        b1 = b2 = 0
+        player = 1
+        for _ in range(int(rng.randint(0, max_plies + 1))):
+            m = co.legal_mask(b1, b2)
+            cols = [c for c in range(7) if (m >> c) & 1]
+            _, b1, b2 = co.drop(b1, b2, player, int(rng.choice(cols)))
+            player = 3 - player
+            if co.lib().orc_is_terminal(b1, b2):
+                break
+        out.append((b1, b2, player))          # finished start positions stay in: they are retired unplayed
+    return out
+
+
+@pytest.mark.parametrize("lockstep", [False, True])
+def test_refill_fixed_evaluator_vs_oracle(gpu, oracle, lockstep):
+    from alphazero_amd.engine import Engine, trajectories_to_numpy
+    co, _ = oracle
+    n, slots, sims = 300, 37, 60
+    pos = _positions(co, n, seed=5, max_plies=30)
+    assert any(co.lib().orc_is_terminal(p[0], p[1]) for p in pos)
+    eng = Engine(max_games=slots, max_sims=sims)
+    try:
+        traj, stats = eng.selfplay_round(n, eng.params(sims, 1.4, evaluator="hash_q8", lockstep=lockstep), first_game_id=500,
+                                         start_boards=np.array([(p[0], p[1]) for p in pos], dtype=np.uint64),
+                                         start_players=np.array([p[2] for p in pos], dtype=np.int8))
+        rec = trajectories_to_numpy(traj)
+    finally:
+        eng.close()
+    plies = 0
+    for i, (b1, b2, player) in enumerate(pos):
+        moves, visits, result, final, _ = co.selfplay_game(sims, 1.4, "hash_q8", b1, b2, player)
+        r = rec[i]
+        assert r["game_id"] == 500 + i
+        assert r["length"] == len(moves), i
+        assert r["plies"]["action"][:len(moves)].tolist() == moves
+        assert r["plies"]["visits"][:len(moves)].tolist() == visits
+        assert r["result"] == (2 if result is None else result)
+        assert (int(r["final_boards"][0]), int(r["final_boards"][1])) == final
+        plies += len(moves)
+    assert stats["games"] == n and stats["plies"] == plies and stats["sims"] == plies * sims
+
+
+def test_refill_az_noise_and_rollouts_independent_of_slot_count(gpu):
+    """PUCT + engine-drawn Dirichlet noise + random rollouts: every draw is addressed by
+    (seed, game id, move index, simulation), so 200 games on 24 slots equal 200 games on 256."""
+    from alphazero_amd.engine import Engine, trajectories_to_numpy
+    out = []
+    for slots in (24, 256):
+        eng = Engine(max_games=slots, max_sims=64)
+        try:
+            p = eng.params(64, 1.4, evaluator="rollout", mode="az", dirichlet_alpha=0.3, dirichlet_eps=0.25, seed=99)
+            traj, stats = eng.selfplay_round(200, p, first_game_id=7)
+            out.append(trajectories_to_numpy(traj).copy())
+            assert stats["games"] == 200
+        finally:
+            eng.close()
+    assert out[0].tobytes() == out[1].tobytes()
+    assert len({r["plies"]["action"][:r["length"]].tobytes() for r in out[0]}) > 100      # games do differ
+
+
+@pytest.mark.parametrize("precision", ["f16", "f32"])
+def test_refill_network_games_independent_of_slot_count(gpu, oracle, precision):
+    from alphazero_amd.engine import Engine, trajectories_to_numpy
+    _, rp = oracle
+    sd = rp.seeded_state_dict(0)
+    out = []
+    for slots in (16, 128):
+        eng = Engine(max_games=slots, max_sims=32, precision=precision)
+        try:
+            eng.load_state_dict(sd)
+            p = eng.params(32, 1.4, evaluator="net", mode="az", dirichlet_alpha=0.3, dirichlet_eps=0.25, seed=3)
+            traj, stats = eng.selfplay_round(100, p)
+            out.append(trajectories_to_numpy(traj).copy())
+        finally:
+            eng.close()
+    assert out[0].tobytes() == out[1].tobytes()

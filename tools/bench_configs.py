@@ -25,14 +25,15 @@ from alphazero_amd.engine import Engine, trajectories_to_numpy  # noqa: E402
 from alphazero_amd.network import seeded_state_dict  # noqa: E402
 
 
-def timed_round(eng, n, params, starters=None, reps=1):
+def timed_round(eng, n, params, starters=None, reps=1, total=None):
+    """`total` games (default n) on an engine of n slots."""
     zeros = np.zeros((n, 2), dtype=np.uint64) if starters is not None else None
     eng.selfplay_round(min(n, 256), params)                     # warm-up (code objects, clocks)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tot = {}
     for r in range(reps):
-        traj, st = eng.selfplay_round(n, params, first_game_id=r * n, start_boards=zeros, start_players=starters)
+        traj, st = eng.selfplay_round(total or n, params, first_game_id=r * n, start_boards=zeros, start_players=starters)
         for k, v in st.items():
             tot[k] = tot.get(k, 0) + v
     torch.cuda.synchronize()
@@ -65,9 +66,10 @@ def main():
         eng = Engine(max_games=G, max_sims=200)
         eng.load_state_dict(seeded_state_dict(0))
         p = eng.params(200, 1.4, evaluator="net", mode="az", dirichlet_alpha=0.3, dirichlet_eps=0.25, seed=11)
-        dt, st, _ = timed_round(eng, G, p)
-        report(f"az: {G} games x 200 sims/move, PUCT + Dirichlet(0.3, eps 0.25), network", dt, st,
-               {"leaf_batch_fill": st["net_leaves"] / max(st["steps"] * G, 1)})
+        for total in (G, 4 * G):
+            dt, st, _ = timed_round(eng, G, p, total=total)
+            report(f"az: {total} games on {G} slots x 200 sims/move, PUCT + Dirichlet(0.3, eps 0.25), network", dt, st,
+                   {"leaf_batch_fill": st["net_leaves"] / max(st["steps"] * G, 1)})
         eng.close()
     if "arena" in a.what:
         eng = Engine(max_games=G, max_sims=400, n_weight_sets=2)
@@ -77,20 +79,13 @@ def main():
         eng.selfplay_round(256, p)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        done, tot, res = 0, {}, []
-        while done < a.arena_games:
-            n = min(G, a.arena_games - done)
-            starters = (1 + (np.arange(done, done + n) % 2)).astype(np.int8)
-            traj, st = eng.selfplay_round(n, p, first_game_id=done, start_boards=np.zeros((n, 2), dtype=np.uint64),
-                                          start_players=starters)
-            res.append(trajectories_to_numpy(traj)["result"].copy())
-            for k, v in st.items():
-                tot[k] = tot.get(k, 0) + v
-            done += n
+        n = a.arena_games
+        starters = (1 + (np.arange(n) % 2)).astype(np.int8)
+        traj, tot = eng.selfplay_round(n, p, start_boards=np.zeros((n, 2), dtype=np.uint64), start_players=starters)
+        res = trajectories_to_numpy(traj)["result"].copy()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        res = np.concatenate(res)
-        report(f"arena: {a.arena_games} games, two networks (seeds 0 and 1), 400 sims/move, rounds of {G}", dt, tot,
+        report(f"arena: {a.arena_games} games, two networks (seeds 0 and 1), 400 sims/move, {G} slots refilled", dt, tot,
                {"wins_colour1": int((res == 1).sum()), "wins_colour2": int((res == -1).sum()),
                 "draws": int(((res != 1) & (res != -1)).sum())})
         eng.close()
