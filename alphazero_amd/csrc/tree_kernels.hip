@@ -400,6 +400,11 @@ __global__ void tree_init_kernel(EngineDev e, SearchDev p, int make_noise, int s
 // Launch with 1024 threads = 16 games per block, one wavefront per game.
 // ---------------------------------------------------------------------------
 constexpr int kStepGames = 16;                    // games (wavefronts) per block of the step kernel
+// Simulations that end in a finished position need no network and are backed up on the spot,
+// but at most this many per step: a game deep in a won position would otherwise run its whole
+// budget inside one launch while the other 15 waves of its block (and the batch) wait.  The
+// order of a game's simulations is unchanged, so results are too; S+1 steps still suffice.
+constexpr int kTerminalSimsPerStep = 3;
 
 template <bool AZ>
 __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e, SearchDev p, int parity) {
@@ -448,7 +453,8 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
         pend = -1;
     }
 
-    while (sims_done < p.sims) {
+    int spot = 0;
+    while (sims_done < p.sims && spot < kTerminalSimsPerStep) {
         int mypath, len, node;
         u64 c1, c2;
         bool terminal;
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
                 backup_path(pool, mypath, len, v, lane);
             }
             wave_mem_sync();
-            ++sims_done; ++term_hits;
+            ++sims_done; ++term_hits; ++spot;
             continue;
         }
         if (!AZ) n_nodes += expand_compat(pool, node, n_nodes, legal, lane);

@@ -67,7 +67,12 @@ def main():
         eng.load_state_dict(seeded_state_dict(0))
         p = eng.params(200, 1.4, evaluator="net", mode="az", dirichlet_alpha=0.3, dirichlet_eps=0.25, seed=11)
         for total in (G, 4 * G):
+            eng.profile(True)
             dt, st, _ = timed_round(eng, G, p, total=total)
+            prof = {k: round(v["avg_ms"], 4) for k, v in eng.profile_report().items()}
+            eng.profile(False)
+            print(json.dumps({"kernel_ms": prof, "steps": st["steps"], "moves_rounds": st["moves_rounds"],
+                              "net_leaves": st["net_leaves"], "terminal_hits": st["terminal_hits"]}))
             report(f"az: {total} games on {G} slots x 200 sims/move, PUCT + Dirichlet(0.3, eps 0.25), network", dt, st,
                    {"leaf_batch_fill": st["net_leaves"] / max(st["steps"] * G, 1)})
         eng.close()
