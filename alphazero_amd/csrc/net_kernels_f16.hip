@@ -693,29 +693,34 @@ __global__ __launch_bounds__(256) void heads_split_kernel(const float *__restric
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    if (wave >= count) return;
+    // the 8 head rows and the linear layer's bias stay in registers for all rows of this wave
+    float4 wv[8][4], bb[4];
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wv[o][i] = reinterpret_cast<const float4 *>(hw + o * 1024)[lane + 64 * i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bb[i] = reinterpret_cast<const float4 *>(fc_bias)[lane + 64 * i];
     for (int row = wave; row < count; row += nwaves) {
         const float4 *p0 = reinterpret_cast<const float4 *>(part + (size_t)row * 1024);
         const float4 *p1 = reinterpret_cast<const float4 *>(part + ((size_t)max_rows + row) * 1024);
-        const float4 *fb = reinterpret_cast<const float4 *>(fc_bias);
         float4 xv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float4 u = p0[lane + 64 * i], v = p1[lane + 64 * i], bb = fb[lane + 64 * i];
-            xv[i].x = fmaxf(u.x + v.x + bb.x, 0.f);
-            xv[i].y = fmaxf(u.y + v.y + bb.y, 0.f);
-            xv[i].z = fmaxf(u.z + v.z + bb.z, 0.f);
-            xv[i].w = fmaxf(u.w + v.w + bb.w, 0.f);
+            float4 u = p0[lane + 64 * i], v = p1[lane + 64 * i];
+            xv[i].x = fmaxf(u.x + v.x + bb[i].x, 0.f);
+            xv[i].y = fmaxf(u.y + v.y + bb[i].y, 0.f);
+            xv[i].z = fmaxf(u.z + v.z + bb[i].z, 0.f);
+            xv[i].w = fmaxf(u.w + v.w + bb[i].w, 0.f);
         }
         float z[8];
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
-            const float4 *wr = reinterpret_cast<const float4 *>(hw + o * 1024);
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float4 wv = wr[lane + 64 * i];
-                s += xv[i].x * wv.x + xv[i].y * wv.y + xv[i].z * wv.z + xv[i].w * wv.w;
-            }
+            for (int i = 0; i < 4; ++i)
+                s += xv[i].x * wv[o][i].x + xv[i].y * wv[o][i].y + xv[i].z * wv[o][i].z + xv[i].w * wv[o][i].w;
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
             z[o] = s + hb[o];
@@ -805,8 +810,8 @@ void launch_net_stage_f16(hipStream_t st, int stage, const NetWeights &w, const 
         break;
     }
     case NET_HEADS: {
-        int blocks = cdiv16(n_max, 4);
-        heads_split_kernel<<<blocks < 1024 ? blocks : 1024, 256, 0, st>>>(b.fcpart, b.max_rows, w.fc_b, w.heads_w,
+        int blocks = cdiv16(n_max, 4);                          // one wave per row, at most 2 blocks per CU
+        heads_split_kernel<<<blocks < 512 ? blocks : 512, 256, 0, st>>>(b.fcpart, b.max_rows, w.fc_b, w.heads_w,
                                                                           w.heads_b, legal, logp_out, value_out,
                                                                           prior_out, count_ptr, n_max);
         break;
