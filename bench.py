@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Self-play throughput benchmark (BASELINE.json config 2 at N=1, config 3 at N>1).
+"""Self-play throughput benchmark: 4096 concurrent games x 200 sims/move per GPU (one GPU at N=1,
+the same per-GPU share on each of N GPUs at N>1).
 
 One "step" = one self-play round: every rank plays GAMES_PER_GPU concurrent Connect Four
 games to the end with the reference's search (200 simulations per move, same searcher
@@ -12,7 +13,8 @@ all-gathered over RCCL.  Weak scaling: per-GPU work is fixed.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     : the dominant kernel's algorithmic FLOP rate against the MI355X f32 matrix peak,
+  roofline     : the dominant kernel's algorithmic FLOP rate against the MI355X dense matrix peak of
+                 the arithmetic in use (f16 inputs: 2.5 PFLOP/s; f32: 157.3 TFLOP/s),
                  its duration measured with HIP events on the launch stream inside this run;
   cpu_baseline : the CPU restatement of the reference path (oracle/ref_port.py: numpy board,
                  one game at a time, batch-1 torch-CPU forward) timed on this box's host cores
