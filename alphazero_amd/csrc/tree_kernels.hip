@@ -619,8 +619,11 @@ __global__ __launch_bounds__(64) void tree_fused_kernel(EngineDev e, SearchDev p
 // Puts game j of the round into slot g; returns false when that game starts from a finished
 // position (its record is then complete and the slot is still free).
 __device__ bool seat_game(const EngineDev &e, const RoundDev &r, int g, int j) {
-    u64 b1 = r.start_boards ? r.start_boards[2 * j] : 0, b2 = r.start_boards ? r.start_boards[2 * j + 1] : 0;
-    int player = r.start_players ? r.start_players[j] : 1;
+    // caller-supplied positions are reduced to something the kernels can index safely: only
+    // the 42 playable bits, no cell owned twice, mover 1 or 2
+    u64 b1 = r.start_boards ? r.start_boards[2 * j] & c4::kBoardMask : 0;
+    u64 b2 = r.start_boards ? r.start_boards[2 * j + 1] & c4::kBoardMask & ~b1 : 0;
+    int player = r.start_players ? (r.start_players[j] == 2 ? 2 : 1) : 1;
     nnb_trajectory *t = r.traj + j;
     t->length = 0; t->result = 2; t->game_id = r.first_game_id + j; t->reserved = 0;
     t->final_boards[0] = b1; t->final_boards[1] = b2;
@@ -723,8 +726,9 @@ __global__ void search_init_kernel(EngineDev e, const u64 *__restrict__ boards,
                                    const float *__restrict__ root_noise) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= e.n_games) return;
-    e.root_boards[2 * g] = boards[2 * g]; e.root_boards[2 * g + 1] = boards[2 * g + 1];
-    e.root_player[g] = players[g];
+    const u64 b1 = boards[2 * g] & c4::kBoardMask, b2 = boards[2 * g + 1] & c4::kBoardMask & ~b1;
+    e.root_boards[2 * g] = b1; e.root_boards[2 * g + 1] = b2;
+    e.root_player[g] = players[g] == 2 ? 2 : 1;
     e.active[g] = 1;
     e.ply[g] = 0;
     e.game_id[g] = game_base + g;

@@ -102,3 +102,28 @@ def test_refill_network_games_independent_of_slot_count(gpu, oracle, precision):
         finally:
             eng.close()
     assert out[0].tobytes() == out[1].tobytes()
+
+
+def test_hostile_start_positions_are_sanitised(gpu):
+    """Arbitrary 64-bit patterns and mover bytes must not take the kernels out of bounds: the engine
+    keeps the 42 playable bits, gives a doubly owned cell to colour 1 and reads any mover but 2 as 1."""
+    from alphazero_amd.engine import Engine, trajectories_to_numpy
+    rng = np.random.RandomState(3)
+    n = 200
+    boards = rng.randint(0, 2 ** 63, size=(n, 2), dtype=np.int64).astype(np.uint64) * np.uint64(2) + np.uint64(1)
+    players = rng.randint(-128, 128, size=n).astype(np.int8)
+    eng = Engine(max_games=64, max_sims=32, n_weight_sets=2)
+    try:
+        for kw in ({"evaluator": "hash_q8"}, {"evaluator": "hash_q8", "lockstep": True, "weight_set_colour2": 1},
+                   {"evaluator": "rollout", "mode": "az", "dirichlet_alpha": 0.3, "dirichlet_eps": 0.25}):
+            traj, stats = eng.selfplay_round(n, eng.params(32, 1.4, **kw), start_boards=boards, start_players=players)
+            rec = trajectories_to_numpy(traj)
+            assert stats["games"] == n
+            mask = np.uint64(0xFDFBF7EFDFBF)
+            assert ((rec["final_boards"] & ~mask) == 0).all()
+            assert ((rec["final_boards"][:, 0] & rec["final_boards"][:, 1]) == 0).all()
+            assert np.isin(rec["result"], (-1, 0, 1, 2)).all()      # 2: no legal move yet not finished (stones in mid-air)
+            v, a, _, _ = eng.search(boards[:64], players[:64], eng.params(32, 1.4, **kw))
+            assert ((a >= -1) & (a < 7)).all()
+    finally:
+        eng.close()
