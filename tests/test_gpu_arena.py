@@ -155,3 +155,40 @@ def test_arena_two_networks(oracle, precision):
                   rec[s - 1]["plies"]["action"][:rec[s - 1]["length"]].tolist())
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("lockstep", [False, True])
+def test_arena_az_mode_fixed_evaluators_vs_oracle(arena_engine, oracle, lockstep):
+    """The same two-evaluator arena under the PUCT rule (priors and values both come from the
+    root mover's evaluator)."""
+    import ctypes as C
+    from alphazero_amd.engine import trajectories_to_numpy
+    co, rp = oracle
+    eng = arena_engine
+    sims, n = 48, 32
+
+    def az_eval(wset):
+        mix = (wset * SET_MIX) & M64
+        def f(me, opp, legal):
+            pri = (C.c_float * 7)()
+            co.lib().orc_fixed_priors(co.EVAL_HASH_Q8, me ^ mix, opp, legal, pri)
+            return list(pri), rp.hash_value_q8(me ^ mix, opp)
+        return f
+    evs = [az_eval(0), az_eval(2)]
+    starters = (1 + np.arange(n) % 2).astype(np.int8)
+    prm = eng.params(sims, 1.25, evaluator="hash_q8", mode="az", lockstep=lockstep, weight_set=0, weight_set_colour2=2)
+    traj, _ = eng.selfplay_round(n, prm, start_boards=np.zeros((n, 2), dtype=np.uint64), start_players=starters)
+    rec = trajectories_to_numpy(traj)
+    for s in (1, 2):
+        b1 = b2 = 0
+        player = s
+        moves, visits = [], []
+        while not co.lib().orc_is_terminal(b1, b2):
+            a, v, _ = co.az_search(b1, b2, player, sims, 1.25, evs[player - 1])
+            moves.append(a); visits.append(v)
+            _, b1, b2 = co.drop(b1, b2, player, a)
+            player = 3 - player
+        for r in rec[s - 1::2]:
+            assert r["plies"]["action"][:r["length"]].tolist() == moves
+            assert r["plies"]["visits"][:len(moves)].tolist() == visits
+            assert r["result"] == co.lib().orc_result(b1, b2)
