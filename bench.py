@@ -106,7 +106,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # Under a launcher (RANK set) the collective path runs even with one rank, so the single-GPU
+    # launch of `python -m torch.distributed.run --nproc-per-node 1 bench.py` exercises RCCL too.
+    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
@@ -115,17 +118,17 @@ def main():
     engine.load_state_dict(seeded_state_dict(0))
     params = engine.params(args.sims, C_PUCT, evaluator="net", mode="compat")
     traj = torch.empty((G, TRAJECTORY_BYTES), dtype=torch.uint8, device=device)
-    replay = torch.empty((world * G, TRAJECTORY_BYTES), dtype=torch.uint8, device=device) if world > 1 else traj
+    replay = torch.empty((world * G, TRAJECTORY_BYTES), dtype=torch.uint8, device=device) if use_dist else traj
 
     def one_round(step_idx: int):
         _, stats = engine.selfplay_round(G, params, first_game_id=(step_idx * world + rank) * G, out=traj)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(replay, traj)      # RCCL: trajectories into every rank's buffer
         return stats
 
     def fence():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -146,14 +149,14 @@ def main():
 
     # all-gather cost alone (reported, also part of the timed region above)
     gather_ms = None
-    if world > 1:
+    if use_dist:
         fence()
         g0 = time.perf_counter()
         dist.all_gather_into_tensor(replay, traj)
         torch.cuda.synchronize(device)
         gather_ms = (time.perf_counter() - g0) * 1e3
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -216,7 +219,7 @@ def main():
                       "mean_selection_depth": depth_mean,
                       "leaf_batch_fill": job["net_leaves"] / max(job["steps"] * G, 1),
                       "allgather_ms": gather_ms,
-                      "allgather_bytes": world * G * TRAJECTORY_BYTES if world > 1 else 0},
+                      "allgather_bytes": world * G * TRAJECTORY_BYTES if use_dist else 0},
             "kernel_ms": {k: round(v["avg_ms"], 4) for k, v in prof.items()},
             "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.precision],
                          "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": traffic,
@@ -232,7 +235,7 @@ def main():
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     engine.close()
