@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "engine_layout.h"
+#include "heads_math.h"
 
 namespace nnb {
 
@@ -13,8 +14,16 @@ void launch_ucb_scores(hipStream_t st, int n, const double *value, const int32_t
                        const int32_t *parent_visits, double c_puct, const double *log_table, int log_n,
                        double *out);
 void launch_tree_init(hipStream_t st, const EngineDev &e, const SearchDev &p, int make_noise, int selfplay);
-void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, int parity);
+// heads: when heads.fused, a wave with a pending leaf computes the network's heads for it from the
+// linear layer's output (batch b of the leaf arrays reads heads.h[b]) instead of reading
+// leaf_value / leaf_prior
+struct HeadsPair {
+    HeadsDev h[2];
+    int32_t fused;
+};
+void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, int parity, const HeadsPair &heads);
 hipError_t prepare_tree_fused(size_t lds_bytes);
+hipError_t prepare_tree_step();
 void launch_tree_fused(hipStream_t st, const EngineDev &e, const SearchDev &p, size_t lds_bytes);
 void launch_readout(hipStream_t st, const EngineDev &e, const SearchDev &p, int32_t *visits_out,
                     int8_t *action_out, double *root_value_out, const RoundDev *round);
@@ -43,10 +52,13 @@ struct NetBuffers {            // activations, channels-last float32
     float *act3;               // [G][9][10][128]
     float *fc;                 // [G][1024]
     float *fcpart;             // [2][G][1024] split-K partial sums (f16 path)
+    float *fc_b1, *fcpart_b1;  // the same two for the second leaf batch of a two-network arena
     int max_rows;              // G
 };
 enum NetStage { NET_CONV0 = 0, NET_CONV2 = 1, NET_CONV4 = 2, NET_FC = 3, NET_HEADS = 4 };
 
+HeadsDev heads_input_f32(const NetWeights &w, const NetBuffers &b);
+HeadsDev heads_input_f16(const NetWeights &w, const NetBuffers &b);
 hipError_t prepare_net_kernels();
 void launch_repack(hipStream_t st, const NetWeights &dst, const float *conv0_w, const float *conv0_b,
                    const float *conv2_w, const float *conv2_b, const float *conv4_w, const float *conv4_b,

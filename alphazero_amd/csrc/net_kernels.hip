@@ -12,6 +12,7 @@
 #include "c4_bits.h"
 #include "engine_layout.h"
 #include "kernels.h"
+#include "heads_math.h"
 
 namespace nnb {
 
@@ -320,10 +321,7 @@ __global__ __launch_bounds__(256, 1) void fc_kernel(const float *__restrict__ a,
 // K6: heads (network.py:40-41,48-49): 1024->7 log-softmax and 1024->1 tanh, plus the
 // legal-move mask / renormalisation of agent_code.py:199-208.  One wave per row.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void heads_kernel(const float *__restrict__ x,     // [rows][1024]
-                                                    const float *__restrict__ hw,    // [8][1024]
-                                                    const float *__restrict__ hb,    // [8]
-                                                    const uint8_t *__restrict__ legal,
+__global__ __launch_bounds__(256) void heads_kernel(HeadsDev hd, const uint8_t *__restrict__ legal,
                                                     float *__restrict__ logp_out, float *__restrict__ value_out,
                                                     float *__restrict__ prior_out,
                                                     const int32_t *__restrict__ count_ptr, int n_fixed) {
@@ -332,54 +330,24 @@ __global__ __launch_bounds__(256) void heads_kernel(const float *__restrict__ x,
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int row = wave; row < count; row += nwaves) {
-        const float4 *xr = reinterpret_cast<const float4 *>(x + (size_t)row * 1024);
         float4 xv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xv[i] = xr[lane + 64 * i];
+        heads_load_row(hd, row, lane, xv);
         float z[8];
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            const float4 *wr = reinterpret_cast<const float4 *>(hw + o * 1024);
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float4 wv = wr[lane + 64 * i];
-                s += xv[i].x * wv.x + xv[i].y * wv.y + xv[i].z * wv.z + xv[i].w * wv.w;
-            }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-            z[o] = s + hb[o];
-        }
+        for (int o = 0; o < 8; ++o)
+            z[o] = heads_dot(xv, reinterpret_cast<const float4 *>(hd.hw + o * 1024), lane) + hd.hb[o];
         if (lane == 0) {
-            float mx = z[0];
-#pragma unroll
-            for (int o = 1; o < 7; ++o) mx = fmaxf(mx, z[o]);
-            float sum = 0.f;
-#pragma unroll
-            for (int o = 0; o < 7; ++o) sum += expf(z[o] - mx);
-            const float lse = mx + logf(sum);
             float lp[7];
-#pragma unroll
-            for (int o = 0; o < 7; ++o) lp[o] = z[o] - lse;
+            heads_log_softmax(z, lp);
             if (logp_out)
 #pragma unroll
                 for (int o = 0; o < 7; ++o) logp_out[(size_t)row * 7 + o] = lp[o];
             if (value_out) value_out[row] = tanhf(z[7]);
             if (prior_out && legal) {
-                // agent_code.py:199-208: exp in float32, mask + renormalise in float64
-                const unsigned mask = legal[row];
-                double f[7], tot = 0.0;
+                float pr[7];
+                heads_priors(lp, legal[row], pr);
 #pragma unroll
-                for (int o = 0; o < 7; ++o) {
-                    f[o] = ((mask >> o) & 1) ? (double)expf(lp[o]) : 0.0;
-                    tot += f[o];
-                }
-                const int nl = __popc(mask);
-#pragma unroll
-                for (int o = 0; o < 7; ++o) {
-                    double pr = tot > 0.0 ? f[o] / tot : (((mask >> o) & 1) ? 1.0 / nl : 0.0);
-                    prior_out[(size_t)row * 7 + o] = (float)pr;
-                }
+                for (int o = 0; o < 7; ++o) prior_out[(size_t)row * 7 + o] = pr[o];
             }
         }
     }
@@ -389,6 +357,10 @@ __global__ __launch_bounds__(256) void heads_kernel(const float *__restrict__ x,
 // Host launchers
 // ---------------------------------------------------------------------------
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+HeadsDev heads_input_f32(const NetWeights &w, const NetBuffers &b) {
+    return HeadsDev{b.fc, nullptr, nullptr, w.heads_w, w.heads_b, 0};
+}
 
 constexpr int CONV2_NB = 4, CONV4_NB = 2;
 constexpr size_t CONV2_LDS = (size_t)(CONV2_NB * 7 * 8 + 1) * 512;
@@ -445,7 +417,7 @@ void launch_net_stage(hipStream_t st, int stage, const NetWeights &w, const NetB
         break;
     case NET_HEADS: {
         int blocks = cdiv(n_max, 4);
-        heads_kernel<<<blocks < 1024 ? blocks : 1024, 256, 0, st>>>(b.fc, w.heads_w, w.heads_b, legal,
+        heads_kernel<<<blocks < 1024 ? blocks : 1024, 256, 0, st>>>(heads_input_f32(w, b), legal,
                                                                     logp_out, value_out, prior_out,
                                                                     count_ptr, n_max);
         break;

@@ -11,6 +11,7 @@
 #include "c4_bits.h"
 #include "engine_layout.h"
 #include "kernels.h"
+#include "heads_math.h"
 
 namespace nnb {
 
@@ -679,13 +680,11 @@ __global__ __launch_bounds__(256, 1) void fc_f16_kernel(const _Float16 *__restri
 
 // ---------------------------------------------------------------------------
 // Heads over split linear-layer partial sums: x = ReLU(part[0] + part[1] + bias), then
-// 1024->7 log-softmax, 1024->1 tanh and the legal-move mask (network.py:40-41,48-49,
-// agent_code.py:199-208).  One wave per row.
+// 1024->7 log-softmax, 1024->1 tanh and the legal-move mask (heads_math.h).  One wave per row;
+// the 8 head rows stay in registers for all rows of a wave.  The search itself does not launch
+// this kernel (the tree step finishes its own leaf); it serves nnb_net_forward and the checks.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void heads_split_kernel(const float *__restrict__ part, int max_rows,
-                                                          const float *__restrict__ fc_bias,
-                                                          const float *__restrict__ hw, const float *__restrict__ hb,
-                                                          const uint8_t *__restrict__ legal,
+__global__ __launch_bounds__(256) void heads_split_kernel(HeadsDev hd, const uint8_t *__restrict__ legal,
                                                           float *__restrict__ logp_out, float *__restrict__ value_out,
                                                           float *__restrict__ prior_out,
                                                           const int32_t *__restrict__ count_ptr, int n_fixed) {
@@ -694,66 +693,41 @@ __global__ __launch_bounds__(256) void heads_split_kernel(const float *__restric
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     if (wave >= count) return;
-    // the 8 head rows and the linear layer's bias stay in registers for all rows of this wave
-    float4 wv[8][4], bb[4];
+    float4 wv[8][4];
 #pragma unroll
     for (int o = 0; o < 8; ++o)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wv[o][i] = reinterpret_cast<const float4 *>(hw + o * 1024)[lane + 64 * i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bb[i] = reinterpret_cast<const float4 *>(fc_bias)[lane + 64 * i];
+        for (int i = 0; i < 4; ++i) wv[o][i] = reinterpret_cast<const float4 *>(hd.hw + o * 1024)[lane + 64 * i];
     for (int row = wave; row < count; row += nwaves) {
-        const float4 *p0 = reinterpret_cast<const float4 *>(part + (size_t)row * 1024);
-        const float4 *p1 = reinterpret_cast<const float4 *>(part + ((size_t)max_rows + row) * 1024);
         float4 xv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float4 u = p0[lane + 64 * i], v = p1[lane + 64 * i];
-            xv[i].x = fmaxf(u.x + v.x + bb[i].x, 0.f);
-            xv[i].y = fmaxf(u.y + v.y + bb[i].y, 0.f);
-            xv[i].z = fmaxf(u.z + v.z + bb[i].z, 0.f);
-            xv[i].w = fmaxf(u.w + v.w + bb[i].w, 0.f);
-        }
+        heads_load_row(hd, row, lane, xv);
         float z[8];
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                s += xv[i].x * wv[o][i].x + xv[i].y * wv[o][i].y + xv[i].z * wv[o][i].z + xv[i].w * wv[o][i].w;
+            for (int i = 0; i < 4; ++i) {
+                s = __builtin_fmaf(xv[i].x, wv[o][i].x, s);
+                s = __builtin_fmaf(xv[i].y, wv[o][i].y, s);
+                s = __builtin_fmaf(xv[i].z, wv[o][i].z, s);
+                s = __builtin_fmaf(xv[i].w, wv[o][i].w, s);
+            }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-            z[o] = s + hb[o];
+            z[o] = s + hd.hb[o];
         }
         if (lane == 0) {
-            float mx = z[0];
-#pragma unroll
-            for (int o = 1; o < 7; ++o) mx = fmaxf(mx, z[o]);
-            float sum = 0.f;
-#pragma unroll
-            for (int o = 0; o < 7; ++o) sum += expf(z[o] - mx);
-            const float lse = mx + logf(sum);
             float lp[7];
-#pragma unroll
-            for (int o = 0; o < 7; ++o) lp[o] = z[o] - lse;
+            heads_log_softmax(z, lp);
             if (logp_out)
 #pragma unroll
                 for (int o = 0; o < 7; ++o) logp_out[(size_t)row * 7 + o] = lp[o];
             if (value_out) value_out[row] = tanhf(z[7]);
             if (prior_out && legal) {
-                const unsigned mask = legal[row];
-                double f[7], tot = 0.0;
+                float pr[7];
+                heads_priors(lp, legal[row], pr);
 #pragma unroll
-                for (int o = 0; o < 7; ++o) {
-                    f[o] = ((mask >> o) & 1) ? (double)expf(lp[o]) : 0.0;
-                    tot += f[o];
-                }
-                const int nl = __popc(mask);
-#pragma unroll
-                for (int o = 0; o < 7; ++o) {
-                    double pr = tot > 0.0 ? f[o] / tot : (((mask >> o) & 1) ? 1.0 / nl : 0.0);
-                    prior_out[(size_t)row * 7 + o] = (float)pr;
-                }
+                for (int o = 0; o < 7; ++o) prior_out[(size_t)row * 7 + o] = pr[o];
             }
         }
     }
@@ -763,6 +737,10 @@ __global__ __launch_bounds__(256) void heads_split_kernel(const float *__restric
 // Host launchers
 // ---------------------------------------------------------------------------
 static inline int cdiv16(int a, int b) { return (a + b - 1) / b; }
+
+HeadsDev heads_input_f16(const NetWeights &w, const NetBuffers &b) {
+    return HeadsDev{b.fcpart, b.fcpart + (size_t)b.max_rows * 1024, w.fc_b, w.heads_w, w.heads_b, b.max_rows};
+}
 
 constexpr int C2H_NB = 4, C4H_NB = 3;
 constexpr size_t conv_lds_bytes(int ih, int iw, int nb) {
@@ -811,9 +789,8 @@ void launch_net_stage_f16(hipStream_t st, int stage, const NetWeights &w, const 
     }
     case NET_HEADS: {
         int blocks = cdiv16(n_max, 4);                          // one wave per row, at most 2 blocks per CU
-        heads_split_kernel<<<blocks < 512 ? blocks : 512, 256, 0, st>>>(b.fcpart, b.max_rows, w.fc_b, w.heads_w,
-                                                                          w.heads_b, legal, logp_out, value_out,
-                                                                          prior_out, count_ptr, n_max);
+        heads_split_kernel<<<blocks < 512 ? blocks : 512, 256, 0, st>>>(heads_input_f16(w, b), legal, logp_out, value_out,
+                                                                        prior_out, count_ptr, n_max);
         break;
     }
     default: break;

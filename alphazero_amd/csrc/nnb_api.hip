@@ -115,6 +115,8 @@ void carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std::v
     b.act3 = c.take<float>(G * 90 * 128);
     b.fc = c.take<float>(G * 1024);
     b.fcpart = c.take<float>(2 * G * 1024);
+    b.fc_b1 = c.take<float>(G * 1024);
+    b.fcpart_b1 = c.take<float>(2 * G * 1024);
     b.max_rows = cfg.max_games;
     w.resize(cfg.n_weight_sets);
     for (auto &s : w) {
@@ -215,26 +217,46 @@ int check_params(nnb_engine *e, const nnb_search_params *p, int n) {
     return NNB_OK;
 }
 
-void net_stage(nnb_engine *e, hipStream_t st, int stage, const NetWeights &w, const u64 *side, const uint8_t *legal,
-               float *logp, float *value, float *prior, const int32_t *count_ptr, int n_max) {
+void net_stage(nnb_engine *e, hipStream_t st, int stage, const NetWeights &w, const NetBuffers &b, const u64 *side,
+               const uint8_t *legal, float *logp, float *value, float *prior, const int32_t *count_ptr, int n_max) {
     if (e->cfg.net_precision == NNB_NET_F32)
-        launch_net_stage(st, stage, w, e->buf, side, legal, logp, value, prior, count_ptr, n_max);
+        launch_net_stage(st, stage, w, b, side, legal, logp, value, prior, count_ptr, n_max);
     else
-        launch_net_stage_f16(st, stage, w, e->buf, side, legal, logp, value, prior, count_ptr, n_max);
+        launch_net_stage_f16(st, stage, w, b, side, legal, logp, value, prior, count_ptr, n_max);
 }
 
-// Forward pass over one of the engine's compacted leaf batches (count on the device).
-void forward_leaves(nnb_engine *e, hipStream_t st, int weight_set, int batch, const int32_t *count_ptr, int n_max) {
+// Activation buffers of leaf batch `batch`: the convolutions' buffers are shared (the batches run
+// one after the other), the linear layer's output is per batch because the tree step reads it later.
+NetBuffers batch_buffers(const nnb_engine *e, int batch) {
+    NetBuffers b = e->buf;
+    if (batch == 1) { b.fc = b.fc_b1; b.fcpart = b.fcpart_b1; }
+    return b;
+}
+
+HeadsDev heads_input(const nnb_engine *e, int weight_set, int batch) {
+    const NetBuffers b = batch_buffers(e, batch);
+    return e->cfg.net_precision == NNB_NET_F32 ? heads_input_f32(e->weights[weight_set], b)
+                                               : heads_input_f16(e->weights[weight_set], b);
+}
+
+// Forward pass over one of the engine's compacted leaf batches (count on the device).  With
+// `with_heads` false it stops after the linear layer; the tree step computes the heads.
+void forward_leaves(nnb_engine *e, hipStream_t st, int weight_set, int batch, const int32_t *count_ptr, int n_max,
+                    bool with_heads) {
     const NetWeights &w = e->weights[weight_set];
     const EngineDev &d = e->dev;
+    const NetBuffers nb = batch_buffers(e, batch);
     const size_t o = (size_t)batch * d.max_games;
     const bool fused_in = e->cfg.net_precision == NNB_NET_F16;     // conv0 is part of the conv2 launch there
-    if (!fused_in) { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, d.leaf_side + 2 * o, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
-    { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, d.leaf_side + 2 * o, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
-    { ProfScope ps(e, 3, st); net_stage(e, st, NET_CONV4, w, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
-    { ProfScope ps(e, 4, st); net_stage(e, st, NET_FC, w, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
-    { ProfScope ps(e, 5, st); net_stage(e, st, NET_HEADS, w, nullptr, d.leaf_legal + o, d.leaf_logp + 7 * o, d.leaf_value + o, d.leaf_prior + 7 * o, count_ptr,
-                                        n_max); }
+    if (!fused_in) { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, nb, d.leaf_side + 2 * o, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
+    { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, nb, d.leaf_side + 2 * o, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
+    { ProfScope ps(e, 3, st); net_stage(e, st, NET_CONV4, w, nb, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
+    { ProfScope ps(e, 4, st); net_stage(e, st, NET_FC, w, nb, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
+    if (with_heads) {
+        ProfScope ps(e, 5, st);
+        net_stage(e, st, NET_HEADS, w, nb, nullptr, d.leaf_legal + o, d.leaf_logp + 7 * o, d.leaf_value + o, d.leaf_prior + 7 * o, count_ptr,
+                  n_max);
+    }
 }
 
 // One move for every live game: S simulations, then the root readout.
@@ -254,13 +276,17 @@ int run_move(nnb_engine *e, hipStream_t st, const nnb_search_params &p, int32_t 
     }
     launch_tree_init(st, d, sd, make_noise, selfplay);
     if (p.evaluator == NNB_EVAL_NET || (p.flags & NNB_FLAG_LOCKSTEP)) {
+        const int nbatch = sd.wset[0] == sd.wset[1] ? 1 : 2;
+        HeadsPair heads = {};
+        heads.fused = p.evaluator == NNB_EVAL_NET && !(p.flags & NNB_FLAG_SEPARATE_HEADS);
+        if (heads.fused)
+            for (int b = 0; b < nbatch; ++b) heads.h[b] = heads_input(e, sd.wset[b], b);
         for (int s = 0; s <= p.sims; ++s) {
-            { ProfScope ps(e, 0, st); launch_tree_step(st, d, sd, s & 1); }
+            { ProfScope ps(e, 0, st); launch_tree_step(st, d, sd, s & 1, heads); }
             if (s == p.sims) break;
-            const int nbatch = sd.wset[0] == sd.wset[1] ? 1 : 2;
             for (int b = 0; b < nbatch; ++b) {
                 const int32_t *cnt = d.leaf_count + 2 * (s & 1) + b;
-                if (p.evaluator == NNB_EVAL_NET) forward_leaves(e, st, sd.wset[b], b, cnt, d.n_games);
+                if (p.evaluator == NNB_EVAL_NET) forward_leaves(e, st, sd.wset[b], b, cnt, d.n_games, !heads.fused);
                 else launch_fixed_eval(st, d, sd, b, cnt);
             }
         }
@@ -349,6 +375,7 @@ int nnb_engine_create(const nnb_config *cfg, void *workspace, size_t workspace_b
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->host_counters), 64 * sizeof(int32_t), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->host_stats), 32 * sizeof(unsigned long long), hipHostMallocDefault));
     HIP_TRY(prepare_net_kernels());
+    HIP_TRY(prepare_tree_step());
     HIP_TRY(prepare_net_kernels_f16());
     HIP_TRY(hipStreamSynchronize(st));
     *engine_out = e;
@@ -431,11 +458,11 @@ int nnb_net_forward(nnb_engine *e, int weight_set, void *stream, int32_t n, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     const NetWeights &w = e->weights[weight_set];
     const u64 *side = reinterpret_cast<const u64 *>(side_boards);
-    { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, side, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
-    { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, side, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
-    { ProfScope ps(e, 3, st); net_stage(e, st, NET_CONV4, w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
-    { ProfScope ps(e, 4, st); net_stage(e, st, NET_FC, w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
-    { ProfScope ps(e, 5, st); net_stage(e, st, NET_HEADS, w, nullptr, legal_masks, log_policy_out, value_out, priors_out, nullptr, n); }
+    { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, e->buf, side, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+    { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, e->buf, side, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+    { ProfScope ps(e, 3, st); net_stage(e, st, NET_CONV4, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+    { ProfScope ps(e, 4, st); net_stage(e, st, NET_FC, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+    { ProfScope ps(e, 5, st); net_stage(e, st, NET_HEADS, w, e->buf, nullptr, legal_masks, log_policy_out, value_out, priors_out, nullptr, n); }
     HIP_TRY(hipGetLastError());
     return NNB_OK;
 }

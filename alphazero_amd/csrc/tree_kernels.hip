@@ -406,12 +406,26 @@ constexpr int kStepGames = 16;                    // games (wavefronts) per bloc
 // order of a game's simulations is unchanged, so results are too; S+1 steps still suffice.
 constexpr int kTerminalSimsPerStep = 3;
 
-template <bool AZ>
-__global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e, SearchDev p, int parity) {
+// HEADS: the network's heads for the pending leaf are computed here, by the wave that owns the
+// game, from the linear layer's output - no separate heads launch, no round trip of values and
+// priors through memory.  The head rows the block needs are staged in LDS first (the value row
+// only under the reference rule, which ignores priors; all 8 rows under PUCT; per batch).
+template <bool AZ, bool HEADS>
+__global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e, SearchDev p, int parity, HeadsPair hp) {
     __shared__ int s_want[kStepGames];       // 0 = no leaf, 1 + batch otherwise
     __shared__ int s_base[2];
+    extern __shared__ __attribute__((aligned(16))) float4 s_hw[];      // [batches][HROWS][256]
+    constexpr int HROWS = AZ ? 8 : 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int g = blockIdx.x * kStepGames + wv;
+    if constexpr (HEADS) {
+        const int nb = p.wset[0] != p.wset[1] ? 2 : 1;
+        for (int i = threadIdx.x; i < nb * HROWS * 256; i += kStepGames * 64) {
+            const int b = i / (HROWS * 256), r = i % (HROWS * 256);
+            s_hw[i] = reinterpret_cast<const float4 *>(hp.h[b].hw + (AZ ? 0 : 7 * 1024))[r];
+        }
+        __syncthreads();
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) { e.leaf_count[2 * (parity ^ 1)] = 0; e.leaf_count[2 * (parity ^ 1) + 1] = 0; }
     const bool live = g < e.n_games && e.active[g];
     const bool two_batches = p.wset[0] != p.wset[1];
@@ -436,11 +450,33 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
     if (pend >= 0) {
         int len = e.path_len[g];
         int mypath = e.path[g * kPathSlots + lane];
-        double v = (double)e.leaf_value[pend];           // value.item(), agent_code.py:213
+        double v;
+        float pr = 0.0f;
+        if constexpr (HEADS) {
+            const int b = pend >= e.max_games ? 1 : 0;
+            const HeadsDev &hd = hp.h[b];
+            float4 xv[4];
+            heads_load_row(hd, (size_t)(pend - b * e.max_games), lane, xv);
+            const float4 *hw = s_hw + b * HROWS * 256;
+            if constexpr (AZ) {
+                float z[8], lp[7], pri[7];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) z[o] = heads_dot(xv, hw + o * 256, lane) + hd.hb[o];
+                heads_log_softmax(z, lp);
+                heads_priors(lp, e.leaf_legal[pend], pri);
+#pragma unroll
+                for (int o = 0; o < 7; ++o) pr = lane == o ? pri[o] : pr;
+                v = (double)tanhf(z[7]);
+            } else {
+                v = (double)tanhf(heads_dot(xv, hw, lane) + hd.hb[7]);   // value.item(), agent_code.py:213
+            }
+        } else {
+            v = (double)e.leaf_value[pend];              // value.item(), agent_code.py:213
+            if (AZ) pr = lane < 7 ? e.leaf_prior[pend * 7 + lane] : 0.0f;
+        }
         if (AZ) {
             const int leaf = __shfl(mypath, len - 1);
             const unsigned legal = e.leaf_legal[pend];
-            float pr = lane < 7 ? e.leaf_prior[pend * 7 + lane] : 0.0f;
             if (len == 1 && p.dirichlet_eps > 0.0 && lane < 7)
                 pr = (float)((1.0 - p.dirichlet_eps) * (double)pr + p.dirichlet_eps * (double)e.root_noise[7 * g + lane]);
             n_nodes += expand_az(pool, prior, leaf, n_nodes, legal, pr, lane);
@@ -796,10 +832,17 @@ void launch_tree_init(hipStream_t st, const EngineDev &e, const SearchDev &p, in
     tree_init_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, p, make_noise, selfplay);
 }
 
-void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, int parity) {
-    const int blocks = cdiv(e.n_games, kStepGames);
-    if (p.mode == NNB_MODE_AZ) tree_step_kernel<true><<<blocks, kStepGames * 64, 0, st>>>(e, p, parity);
-    else tree_step_kernel<false><<<blocks, kStepGames * 64, 0, st>>>(e, p, parity);
+void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, int parity, const HeadsPair &heads) {
+    const int blocks = cdiv(e.n_games, kStepGames), threads = kStepGames * 64;
+    const bool az = p.mode == NNB_MODE_AZ;
+    if (heads.fused) {
+        const size_t lds = (size_t)(p.wset[0] != p.wset[1] ? 2 : 1) * (az ? 8 : 1) * 4096;
+        if (az) tree_step_kernel<true, true><<<blocks, threads, lds, st>>>(e, p, parity, heads);
+        else tree_step_kernel<false, true><<<blocks, threads, lds, st>>>(e, p, parity, heads);
+    } else {
+        if (az) tree_step_kernel<true, false><<<blocks, threads, 0, st>>>(e, p, parity, heads);
+        else tree_step_kernel<false, false><<<blocks, threads, 0, st>>>(e, p, parity, heads);
+    }
 }
 
 hipError_t prepare_tree_fused(size_t lds_bytes) {
@@ -808,6 +851,12 @@ hipError_t prepare_tree_fused(size_t lds_bytes) {
     if (err != hipSuccess) return err;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(tree_fused_kernel<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}
+
+// The PUCT step kernel of a two-network arena stages 2 x 8 head rows = 64 KB of dynamic LDS.
+hipError_t prepare_tree_step() {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(tree_step_kernel<true, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4096);
 }
 
 void launch_tree_fused(hipStream_t st, const EngineDev &e, const SearchDev &p, size_t lds_bytes) {

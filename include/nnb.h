@@ -70,7 +70,11 @@ enum nnb_flags {
     /* Run a fixed evaluator through the lock-step path (tree step kernel, leaf batch,
      * value buffer) that NET uses, instead of the fused one-launch kernel.  Same
      * results; exists so the lock-step machinery can be checked bit for bit. */
-    NNB_FLAG_LOCKSTEP = 1
+    NNB_FLAG_LOCKSTEP = 1,
+    /* NET evaluator: run the network's heads as a kernel of their own after the linear layer
+     * (values and priors of the leaf batch go through the engine's buffers) instead of inside
+     * the tree step.  Same results; exists so the two forms can be checked against each other. */
+    NNB_FLAG_SEPARATE_HEADS = 2
 };
 
 /* How the network's three big layers multiply.  Both accumulate in float32 and keep bias,

@@ -1,0 +1,49 @@
+"""The tree step finishes the forward pass of its own pending leaf (heads of network.py:40-41,48-49
+and the mask / renormalisation of agent_code.py:199-208) instead of reading values and priors a
+separate heads kernel wrote.  Both forms share their arithmetic, so whole self-play rounds must
+come out byte for byte the same."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rp():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (torch.cuda.is_available() is False)")
+    from oracle import ref_port
+    return ref_port
+
+
+@pytest.mark.parametrize("precision", ["f16", "f32"])
+@pytest.mark.parametrize("mode", ["compat", "az"])
+def test_fused_and_separate_heads_agree(rp, precision, mode):
+    from alphazero_amd.engine import Engine, trajectories_to_numpy
+    eng = Engine(max_games=48, max_sims=32, n_weight_sets=2, precision=precision)
+    try:
+        eng.load_state_dict(rp.seeded_state_dict(0), 0)
+        eng.load_state_dict(rp.seeded_state_dict(1), 1)
+        n = 80                                            # more games than slots: refill is exercised too
+        starters = (1 + np.arange(n) % 2).astype(np.int8)
+        zeros = np.zeros((n, 2), dtype=np.uint64)
+        extra = dict(dirichlet_alpha=0.3, dirichlet_eps=0.25, seed=5) if mode == "az" else {}
+        for sets in ({}, {"weight_set": 0, "weight_set_colour2": 1}):
+            out = []
+            for separate in (False, True):
+                prm = eng.params(32, 1.4, evaluator="net", mode=mode, separate_heads=separate, **extra, **sets)
+                traj, stats = eng.selfplay_round(n, prm, start_boards=zeros, start_players=starters)
+                out.append((trajectories_to_numpy(traj).copy(), stats))
+            assert out[0][0].tobytes() == out[1][0].tobytes()
+            assert out[0][1] == out[1][1]
+            if mode == "az":
+                assert len({r["plies"]["action"][:r["length"]].tobytes() for r in out[0][0]}) > 20
+        # single searches too (the root value is the sum of the leaf values the heads produced)
+        boards = np.zeros((48, 2), dtype=np.uint64)
+        players = np.ones(48, dtype=np.int8)
+        a = eng.search(boards, players, eng.params(32, 1.4, evaluator="net", mode=mode, **extra))
+        b = eng.search(boards, players, eng.params(32, 1.4, evaluator="net", mode=mode, separate_heads=True, **extra))
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[2].tobytes() == b[2].tobytes()
+    finally:
+        eng.close()
