@@ -54,7 +54,9 @@ struct EngineDev {
     // root mover is colour 1 go to batch 0 and those of colour 2 to batch 1; otherwise only
     // batch 0 is used.
     u64     *leaf_side;         // [2G][2] side boards (me, opp)
-    uint8_t *leaf_legal;        // [2G]    legal mask of each batched leaf
+    uint8_t *leaf_legal;        // [2][2G] legal mask of each batched leaf, indexed by [step parity][slot]: a step
+                                //         reads the masks of the leaves it consumes while other blocks already
+                                //         write those of the next batch
     int32_t *leaf_count;        // [2][2]  batch sizes, indexed by [step parity][batch]
     float   *leaf_value;        // [2G]    network / evaluator value per batch slot
     float   *leaf_logp;         // [2G][7] network log-policy per batch slot
@@ -73,6 +75,7 @@ struct RoundDev {
     int32_t first_game_id;
 };
 constexpr int kRefills = 16;    // index into EngineDev::counters; entries 0..15 are cleared every move
+constexpr int kLive = 17;       // slots that still hold a game (kept through a whole round)
 
 struct SearchDev {
     int32_t mode;

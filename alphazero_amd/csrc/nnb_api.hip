@@ -103,7 +103,7 @@ void carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std::v
     d.move_index = c.take<int32_t>(G);
     d.root_noise = c.take<float>(7 * G);
     d.leaf_side = c.take<u64>(4 * G);
-    d.leaf_legal = c.take<uint8_t>(2 * G);
+    d.leaf_legal = c.take<uint8_t>(4 * G);
     d.leaf_count = c.take<int32_t>(64);
     d.leaf_value = c.take<float>(2 * G);
     d.leaf_logp = c.take<float>(14 * G);
@@ -241,8 +241,8 @@ HeadsDev heads_input(const nnb_engine *e, int weight_set, int batch) {
 
 // Forward pass over one of the engine's compacted leaf batches (count on the device).  With
 // `with_heads` false it stops after the linear layer; the tree step computes the heads.
-void forward_leaves(nnb_engine *e, hipStream_t st, int weight_set, int batch, const int32_t *count_ptr, int n_max,
-                    bool with_heads) {
+void forward_leaves(nnb_engine *e, hipStream_t st, int weight_set, int batch, int parity, int n_max, bool with_heads) {
+    const int32_t *count_ptr = e->dev.leaf_count + 2 * parity + batch;
     const NetWeights &w = e->weights[weight_set];
     const EngineDev &d = e->dev;
     const NetBuffers nb = batch_buffers(e, batch);
@@ -254,8 +254,36 @@ void forward_leaves(nnb_engine *e, hipStream_t st, int weight_set, int batch, co
     { ProfScope ps(e, 4, st); net_stage(e, st, NET_FC, w, nb, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
     if (with_heads) {
         ProfScope ps(e, 5, st);
-        net_stage(e, st, NET_HEADS, w, nb, nullptr, d.leaf_legal + o, d.leaf_logp + 7 * o, d.leaf_value + o, d.leaf_prior + 7 * o, count_ptr,
+        net_stage(e, st, NET_HEADS, w, nb, nullptr, d.leaf_legal + (size_t)parity * 2 * d.max_games + o, d.leaf_logp + 7 * o, d.leaf_value + o, d.leaf_prior + 7 * o, count_ptr,
                   n_max);
+    }
+}
+
+// What one lock-step round launches besides the tree step.
+struct StepPlan {
+    int nbatch;             // leaf batches in use (2 in a two-network arena)
+    HeadsPair heads;        // inputs of the heads the tree step computes itself
+};
+
+StepPlan make_step_plan(nnb_engine *e, const nnb_search_params &p, const SearchDev &sd) {
+    StepPlan plan = {};
+    plan.nbatch = sd.wset[0] == sd.wset[1] ? 1 : 2;
+    plan.heads.fused = p.evaluator == NNB_EVAL_NET && !(p.flags & NNB_FLAG_SEPARATE_HEADS);
+    if (plan.heads.fused)
+        for (int b = 0; b < plan.nbatch; ++b) plan.heads.h[b] = heads_input(e, sd.wset[b], b);
+    return plan;
+}
+
+// One lock-step round: the tree step of every live game, then (unless it is the closing step of a
+// move) the evaluation of the leaves it batched.
+void lockstep_step(nnb_engine *e, hipStream_t st, const nnb_search_params &p, const SearchDev &sd, const StepPlan &plan,
+                   int parity, bool evaluate) {
+    const EngineDev &d = e->dev;
+    { ProfScope ps(e, 0, st); launch_tree_step(st, d, sd, parity, plan.heads); }
+    if (!evaluate) return;
+    for (int b = 0; b < plan.nbatch; ++b) {
+        if (p.evaluator == NNB_EVAL_NET) forward_leaves(e, st, sd.wset[b], b, parity, d.n_games, !plan.heads.fused);
+        else launch_fixed_eval(st, d, sd, b, parity);
     }
 }
 
@@ -276,20 +304,8 @@ int run_move(nnb_engine *e, hipStream_t st, const nnb_search_params &p, int32_t 
     }
     launch_tree_init(st, d, sd, make_noise, selfplay);
     if (p.evaluator == NNB_EVAL_NET || (p.flags & NNB_FLAG_LOCKSTEP)) {
-        const int nbatch = sd.wset[0] == sd.wset[1] ? 1 : 2;
-        HeadsPair heads = {};
-        heads.fused = p.evaluator == NNB_EVAL_NET && !(p.flags & NNB_FLAG_SEPARATE_HEADS);
-        if (heads.fused)
-            for (int b = 0; b < nbatch; ++b) heads.h[b] = heads_input(e, sd.wset[b], b);
-        for (int s = 0; s <= p.sims; ++s) {
-            { ProfScope ps(e, 0, st); launch_tree_step(st, d, sd, s & 1, heads); }
-            if (s == p.sims) break;
-            for (int b = 0; b < nbatch; ++b) {
-                const int32_t *cnt = d.leaf_count + 2 * (s & 1) + b;
-                if (p.evaluator == NNB_EVAL_NET) forward_leaves(e, st, sd.wset[b], b, cnt, d.n_games, !heads.fused);
-                else launch_fixed_eval(st, d, sd, b, cnt);
-            }
-        }
+        const StepPlan plan = make_step_plan(e, p, sd);
+        for (int s = 0; s <= p.sims; ++s) lockstep_step(e, st, p, sd, plan, s & 1, s < p.sims);
         *steps += p.sims;
     } else {
         size_t lds = (size_t)d.pool_cap * sizeof(Node) +
@@ -515,8 +531,40 @@ int nnb_selfplay_round(nnb_engine *e, void *stream, const nnb_search_params *par
     HIP_TRY(hipMemcpyAsync(e->host_counters, e->dev.counters, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     long long steps = 0, rounds = 0;
-    const long long max_rounds = ((long long)n_games / (slots > 0 ? slots : 1) + 2) * (kMaxPlies + 1);
     int live = e->host_counters[0];
+    const bool lockstep = params->evaluator == NNB_EVAL_NET || (params->flags & NNB_FLAG_LOCKSTEP);
+    if (lockstep && !(params->flags & NNB_FLAG_SYNC_MOVES)) {
+        // No common move boundary: before every tree step the turnover kernel ends the move of the
+        // games whose budget is used up and starts their next search; the host only looks at the
+        // number of occupied slots every kChunk rounds.
+        SearchDev sd = to_dev(*params);
+        const bool az = params->mode == NNB_MODE_AZ;
+        if (!az) { sd.dirichlet_eps = 0.0; sd.dirichlet_alpha = 0.0; }
+        int make_noise = 0;
+        if (az && sd.dirichlet_eps > 0.0) {
+            if (!(sd.dirichlet_alpha > 0.0)) return fail(NNB_ERR_ARG, "dirichlet_eps > 0 needs dirichlet_alpha > 0");
+            make_noise = 1;
+        }
+        const StepPlan plan = make_step_plan(e, *params, sd);
+        constexpr int kChunk = 64;
+        e->prof_stride = kChunk / kProfSamples + 1;
+        launch_tree_init(st, e->dev, sd, make_noise, 1);
+        const long long max_steps = ((long long)n_games / (slots > 0 ? slots : 1) + 2) * (kMaxPlies + 1) * (params->sims + 1);
+        while (live > 0 && steps < max_steps) {
+            for (int k = 0; k < kChunk; ++k, ++steps) {
+                launch_turnover(st, e->dev, sd, round, make_noise);
+                lockstep_step(e, st, *params, sd, plan, (int)(steps & 1), true);
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(e->host_counters, e->dev.counters + kLive, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            prof_drain(e);
+            live = e->host_counters[0];
+        }
+        rounds = (steps + params->sims) / (params->sims + 1);
+        return collect_stats(e, st, stats_out, steps, rounds, n_games);
+    }
+    const long long max_rounds = ((long long)n_games / (slots > 0 ? slots : 1) + 2) * (kMaxPlies + 1);
     while (live > 0 && rounds < max_rounds) {
         HIP_TRY(hipMemsetAsync(e->dev.counters, 0, 16 * sizeof(int32_t), st));
         rc = run_move(e, st, *params, nullptr, nullptr, nullptr, &round, false, &steps);

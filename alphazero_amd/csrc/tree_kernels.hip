@@ -369,11 +369,7 @@ __device__ __forceinline__ double fixed_eval_az(const SearchDev &p, u64 c1, u64 
 // (agent_code.py:159-160).  AZ: root.visits = 0 and, when alpha > 0, fresh Dirichlet
 // noise for the root unless the caller supplied it.
 // ---------------------------------------------------------------------------
-__global__ void tree_init_kernel(EngineDev e, SearchDev p, int make_noise, int selfplay) {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g == 0) { e.leaf_count[0] = 0; e.leaf_count[1] = 0; e.leaf_count[2] = 0; e.leaf_count[3] = 0; }
-    if (g >= e.n_games) return;
-    if (!e.active[g]) return;
+__device__ void init_search(const EngineDev &e, const SearchDev &p, int g, int make_noise, int selfplay) {
     Node r;
     r.value = 0.0; r.visits = p.mode == NNB_MODE_AZ ? 0 : 1; r.first_child = 0; r.nchild = 0; r.action = 0xFF;
     e.nodes[(size_t)g * e.pool_cap] = r;
@@ -387,6 +383,14 @@ __global__ void tree_init_kernel(EngineDev e, SearchDev p, int make_noise, int s
         dirichlet_noise(p.seed, (uint32_t)e.game_id[g], (uint32_t)e.move_index[g], legal, p.dirichlet_alpha,
                         e.root_noise + 7 * g);
     }
+}
+
+__global__ void tree_init_kernel(EngineDev e, SearchDev p, int make_noise, int selfplay) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) { e.leaf_count[0] = 0; e.leaf_count[1] = 0; e.leaf_count[2] = 0; e.leaf_count[3] = 0; }
+    if (g >= e.n_games) return;
+    if (!e.active[g]) return;
+    init_search(e, p, g, make_noise, selfplay);
 }
 
 // ---------------------------------------------------------------------------
@@ -446,6 +450,8 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
     const u64 r1 = e.root_boards[2 * g], r2 = e.root_boards[2 * g + 1];
     batch = two_batches ? player - 1 : 0;      // every leaf of a search is judged by the root mover's network
 
+    // masks of the leaves batched by the previous step (this step writes the other half)
+    const uint8_t *legal_in = e.leaf_legal + (size_t)(parity ^ 1) * 2 * e.max_games;
     int pend = e.pending[g];
     if (pend >= 0) {
         int len = e.path_len[g];
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
 #pragma unroll
                 for (int o = 0; o < 8; ++o) z[o] = heads_dot(xv, hw + o * 256, lane) + hd.hb[o];
                 heads_log_softmax(z, lp);
-                heads_priors(lp, e.leaf_legal[pend], pri);
+                heads_priors(lp, legal_in[pend], pri);
 #pragma unroll
                 for (int o = 0; o < 7; ++o) pr = lane == o ? pri[o] : pr;
                 v = (double)tanhf(z[7]);
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
         }
         if (AZ) {
             const int leaf = __shfl(mypath, len - 1);
-            const unsigned legal = e.leaf_legal[pend];
+            const unsigned legal = legal_in[pend];
             if (len == 1 && p.dirichlet_eps > 0.0 && lane < 7)
                 pr = (float)((1.0 - p.dirichlet_eps) * (double)pr + p.dirichlet_eps * (double)e.root_noise[7 * g + lane]);
             n_nodes += expand_az(pool, prior, leaf, n_nodes, legal, pr, lane);
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
         if (lane == 0) {
             e.leaf_side[2 * slot] = leaf_me;
             e.leaf_side[2 * slot + 1] = leaf_opp;
-            e.leaf_legal[slot] = (uint8_t)leaf_legal_mask;
+            e.leaf_legal[(size_t)parity * 2 * e.max_games + slot] = (uint8_t)leaf_legal_mask;
             e.path_len[g] = leaf_len;
         }
         e.path[g * kPathSlots + lane] = (uint16_t)leaf_path;
@@ -677,12 +683,9 @@ __device__ bool seat_game(const EngineDev &e, const RoundDev &r, int g, int j) {
     return true;
 }
 
-__global__ void readout_kernel(EngineDev e, SearchDev p, int32_t *__restrict__ visits_out,
-                               int8_t *__restrict__ action_out, double *__restrict__ root_value_out,
-                               RoundDev round, int selfplay) {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= e.n_games) return;
-    if (!e.active[g]) return;
+__device__ void readout_game(const EngineDev &e, const SearchDev &p, int g, int32_t *__restrict__ visits_out,
+                             int8_t *__restrict__ action_out, double *__restrict__ root_value_out,
+                             const RoundDev &round, int selfplay) {
     const Node *pool = e.nodes + (size_t)g * e.pool_cap;
     Node root = pool[0];
     int vis[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -732,10 +735,32 @@ __global__ void readout_kernel(EngineDev e, SearchDev p, int32_t *__restrict__ v
             if (j >= round.total_games) break;
             seated = seat_game(e, round, g, j);
         }
-        if (!seated) e.active[g] = 0;
+        if (!seated) { e.active[g] = 0; atomicSub(&e.counters[kLive], 1); }
         done = !seated;
     }
     if (!done) atomicAdd(&e.counters[0], 1);
+}
+
+__global__ void readout_kernel(EngineDev e, SearchDev p, int32_t *__restrict__ visits_out,
+                               int8_t *__restrict__ action_out, double *__restrict__ root_value_out,
+                               RoundDev round, int selfplay) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= e.n_games) return;
+    if (!e.active[g]) return;
+    readout_game(e, p, g, visits_out, action_out, root_value_out, round, selfplay);
+}
+
+// Self-play without a common move boundary: launched before every tree step, it ends the move
+// of exactly those games whose simulation budget is used up (root readout, move, trajectory,
+// retirement or the next game of the round) and starts their next search.  Games that search
+// long positions no longer hold back games that are done, so the leaf batch stays full.
+__global__ void turnover_kernel(EngineDev e, SearchDev p, RoundDev round, int make_noise) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= e.n_games) return;
+    if (!e.active[g]) return;
+    if (e.pending[g] >= 0 || e.sims_done[g] < p.sims) return;
+    readout_game(e, p, g, nullptr, nullptr, nullptr, round, 1);
+    if (e.active[g]) init_search(e, p, g, make_noise, 1);
 }
 
 // Self-play set-up: slot g starts with game g of the round - the empty board
@@ -753,7 +778,7 @@ __global__ void selfplay_init_kernel(EngineDev e, RoundDev round) {
         seated = seat_game(e, round, g, j);
     }
     e.active[g] = seated ? 1 : 0;
-    if (seated) atomicAdd(&e.counters[0], 1);
+    if (seated) { atomicAdd(&e.counters[0], 1); atomicAdd(&e.counters[kLive], 1); }
 }
 
 // Search-only set-up: caller-supplied roots, every root searched.
@@ -792,14 +817,14 @@ __global__ void stats_reduce_kernel(EngineDev e) {
 
 // Fixed evaluators over the compacted leaf batch: fills the value buffer exactly as the
 // network's heads kernel would, so the lock-step path can be run without weights.
-__global__ void fixed_eval_kernel(EngineDev e, SearchDev p, int batch, const int32_t *__restrict__ count_ptr) {
+__global__ void fixed_eval_kernel(EngineDev e, SearchDev p, int batch, int parity) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= *count_ptr) return;
+    if (i >= e.leaf_count[2 * parity + batch]) return;
     i += batch * e.max_games;
     const u64 me = e.leaf_side[2 * i] ^ set_mix(p.wset[batch]), opp = e.leaf_side[2 * i + 1];
     e.leaf_value[i] = (float)fixed_eval(p.evaluator, me, opp);
     if (p.mode == NNB_MODE_AZ) {
-        const unsigned legal = e.leaf_legal[i];
+        const unsigned legal = e.leaf_legal[(size_t)parity * 2 * e.max_games + i];
         for (int c = 0; c < 7; ++c) e.leaf_prior[7 * i + c] = fixed_prior(p.evaluator, me, opp, legal, c);
     }
 }
@@ -877,6 +902,10 @@ void launch_readout(hipStream_t st, const EngineDev &e, const SearchDev &p, int3
                                                          round ? *round : none, round != nullptr);
 }
 
+void launch_turnover(hipStream_t st, const EngineDev &e, const SearchDev &p, const RoundDev &round, int make_noise) {
+    turnover_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, p, round, make_noise);
+}
+
 void launch_selfplay_init(hipStream_t st, const EngineDev &e, const RoundDev &round) {
     selfplay_init_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, round);
 }
@@ -886,8 +915,8 @@ void launch_search_init(hipStream_t st, const EngineDev &e, const u64 *boards, c
     search_init_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, boards, players, game_base, root_noise);
 }
 
-void launch_fixed_eval(hipStream_t st, const EngineDev &e, const SearchDev &p, int batch, const int32_t *count_ptr) {
-    fixed_eval_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, p, batch, count_ptr);
+void launch_fixed_eval(hipStream_t st, const EngineDev &e, const SearchDev &p, int batch, int parity) {
+    fixed_eval_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, p, batch, parity);
 }
 
 void launch_stats_reduce(hipStream_t st, const EngineDev &e) {

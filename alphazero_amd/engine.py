@@ -95,10 +95,11 @@ class Engine:
     def params(self, sims: int, c_puct: float = 1.4, evaluator="net", mode="compat", weight_set: int = 0,
                dirichlet_alpha: float = 0.0, dirichlet_eps: float = 0.0, seed: int = 0,
                lockstep: bool = False, rng_move_index: int = 0, rng_game_base: int = 0,
-               weight_set_colour2: Optional[int] = None, separate_heads: bool = False) -> SearchParams:
+               weight_set_colour2: Optional[int] = None, separate_heads: bool = False,
+               sync_moves: bool = False) -> SearchParams:
         ev = EVALUATORS[evaluator] if isinstance(evaluator, str) else int(evaluator)
         md = MODES[mode] if isinstance(mode, str) else int(mode)
-        return SearchParams(md, ev, int(sims), int(weight_set), int(bool(lockstep)) | (2 if separate_heads else 0),
+        return SearchParams(md, ev, int(sims), int(weight_set), int(bool(lockstep)) | (2 if separate_heads else 0) | (4 if sync_moves else 0),
                             int(rng_move_index),
                             int(rng_game_base), 0 if weight_set_colour2 is None else int(weight_set_colour2) + 1,
                             float(c_puct), float(dirichlet_alpha), float(dirichlet_eps),

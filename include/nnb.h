@@ -74,7 +74,12 @@ enum nnb_flags {
     /* NET evaluator: run the network's heads as a kernel of their own after the linear layer
      * (values and priors of the leaf batch go through the engine's buffers) instead of inside
      * the tree step.  Same results; exists so the two forms can be checked against each other. */
-    NNB_FLAG_SEPARATE_HEADS = 2
+    NNB_FLAG_SEPARATE_HEADS = 2,
+    /* nnb_selfplay_round on the lock-step path: keep all games on a common move boundary
+     * (S+1 tree steps, then one readout for everybody) instead of letting every game end its
+     * move and start the next one as soon as its own simulations are done.  Same games; the
+     * default keeps the leaf batch fuller when games differ. */
+    NNB_FLAG_SYNC_MOVES = 4
 };
 
 /* How the network's three big layers multiply.  Both accumulate in float32 and keep bias,

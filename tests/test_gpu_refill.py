@@ -127,3 +127,33 @@ def test_hostile_start_positions_are_sanitised(gpu):
             assert ((a >= -1) & (a < 7)).all()
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("mode,evaluator", [("compat", "hash_q8"), ("az", "hash_f32"), ("az", "net"), ("compat", "net")])
+def test_games_without_a_common_move_boundary_equal_synchronised_moves(gpu, oracle, mode, evaluator):
+    """By default every game ends its move and starts the next one as soon as its own simulations
+    are done; with sync_moves all games wait for each other.  The games must not depend on that."""
+    from alphazero_amd.engine import Engine, trajectories_to_numpy
+    co, rp = oracle
+    eng = Engine(max_games=40, max_sims=48, n_weight_sets=2)
+    try:
+        if evaluator == "net":
+            eng.load_state_dict(rp.seeded_state_dict(0), 0)
+            eng.load_state_dict(rp.seeded_state_dict(1), 1)
+        n = 130
+        pos = _positions(co, n, seed=11, max_plies=20)
+        boards = np.array([(p[0], p[1]) for p in pos], dtype=np.uint64)
+        players = np.array([p[2] for p in pos], dtype=np.int8)
+        extra = dict(dirichlet_alpha=0.5, dirichlet_eps=0.25, seed=77) if mode == "az" else {}
+        out = []
+        for sync in (False, True):
+            prm = eng.params(48, 1.4, evaluator=evaluator, mode=mode, lockstep=True, sync_moves=sync, weight_set=0,
+                             weight_set_colour2=1, **extra)
+            traj, stats = eng.selfplay_round(n, prm, first_game_id=9, start_boards=boards, start_players=players)
+            out.append((trajectories_to_numpy(traj).copy(), stats))
+        assert out[0][0].tobytes() == out[1][0].tobytes()
+        for k in ("games", "plies", "sims", "net_leaves", "terminal_hits", "depth_sum"):
+            assert out[0][1][k] == out[1][1][k], k
+        assert out[0][1]["steps"] < out[1][1]["steps"]        # fewer lock-step rounds for the same games
+    finally:
+        eng.close()
