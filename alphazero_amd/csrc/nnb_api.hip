@@ -81,7 +81,9 @@ struct nnb_engine {
 
 namespace {
 
-void carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std::vector<NetWeights> &w) {
+// Returns the size of the leading part of the workspace that must start out zeroed (search state);
+// the activation and weight areas behind it are fully overwritten before they are read.
+size_t carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std::vector<NetWeights> &w) {
     const size_t G = cfg.max_games;
     const size_t cap = 1 + 7 * (size_t)cfg.max_sims;
     d.max_games = cfg.max_games; d.pool_cap = (int32_t)cap; d.max_sims = cfg.max_sims; d.n_games = 0;
@@ -110,13 +112,23 @@ void carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std::v
     d.leaf_prior = c.take<float>(14 * G);
     d.counters = c.take<int32_t>(64);
     d.stats64 = c.take<unsigned long long>(32);
-    b.act1 = c.take<float>(G * 56 * 128);
-    b.act2 = c.take<float>(G * 72 * 128);
-    b.act3 = c.take<float>(G * 90 * 128);
-    b.fc = c.take<float>(G * 1024);
-    b.fcpart = c.take<float>(2 * G * 1024);
-    b.fc_b1 = c.take<float>(G * 1024);
-    b.fcpart_b1 = c.take<float>(2 * G * 1024);
+    c.take<unsigned char>(kAlign);
+    const size_t state_bytes = c.off;
+    if (cfg.net_precision == NNB_NET_F32) {
+        b.act1 = c.take<float>(G * 56 * 128);
+        b.act2 = c.take<float>(G * 72 * 128);
+        b.act3 = c.take<float>(G * 90 * 128);
+        b.fc = c.take<float>(G * 1024);
+        b.fc_b1 = c.take<float>(G * 1024);
+        b.fcpart = b.fcpart_b1 = nullptr;
+    } else {                                // half activations; the 2->128 layer's output stays in LDS
+        b.act1 = nullptr;
+        b.act2 = reinterpret_cast<float *>(c.take<uint16_t>(G * 72 * 128));
+        b.act3 = reinterpret_cast<float *>(c.take<uint16_t>(G * 90 * 128));
+        b.fc = b.fc_b1 = nullptr;
+        b.fcpart = c.take<float>(2 * G * 1024);
+        b.fcpart_b1 = c.take<float>(2 * G * 1024);
+    }
     b.max_rows = cfg.max_games;
     w.resize(cfg.n_weight_sets);
     for (auto &s : w) {
@@ -132,6 +144,7 @@ void carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std::v
         s.heads_w = c.take<float>(8 * 1024);  s.heads_b = c.take<float>(8);
     }
     c.take<unsigned char>(kAlign);          // tail pad
+    return state_bytes;
 }
 
 int check_cfg(const nnb_config *cfg) {
@@ -375,14 +388,16 @@ int nnb_engine_create(const nnb_config *cfg, void *workspace, size_t workspace_b
         return fail(NNB_ERR_WORKSPACE, "workspace has %zu bytes, %zu needed", workspace_bytes, need);
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(cfg->device));
-    nnb_engine *e = new (std::nothrow) nnb_engine();
+    struct Guard {                          // frees a half-built engine when a step below fails
+        nnb_engine *e;
+        ~Guard() { if (e) nnb_engine_destroy(e); }
+    } guard{new (std::nothrow) nnb_engine()};
+    nnb_engine *e = guard.e;
     if (!e) return fail(NNB_ERR_ARG, "out of host memory");
     e->cfg = *cfg;
     Carver c(workspace);
-    carve(*cfg, c, e->dev, e->buf, e->weights);
+    const size_t state_bytes = carve(*cfg, c, e->dev, e->buf, e->weights);
     e->weights_loaded.assign(cfg->n_weight_sets, 0);
-    // zero everything except the (large, fully overwritten) activation and weight areas
-    size_t state_bytes = reinterpret_cast<unsigned char *>(e->buf.act1) - static_cast<unsigned char *>(workspace);
     HIP_TRY(hipMemsetAsync(workspace, 0, state_bytes, st));
     // log(n + 1) from the host's libm: the same function CPython's math.log calls (mcts.py:29)
     std::vector<double> logt(cfg->max_sims + 8);
@@ -394,6 +409,7 @@ int nnb_engine_create(const nnb_config *cfg, void *workspace, size_t workspace_b
     HIP_TRY(prepare_tree_step());
     HIP_TRY(prepare_net_kernels_f16());
     HIP_TRY(hipStreamSynchronize(st));
+    guard.e = nullptr;
     *engine_out = e;
     return NNB_OK;
 }
