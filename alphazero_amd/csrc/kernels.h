@@ -21,7 +21,8 @@ struct HeadsPair {
     HeadsDev h[2];
     int32_t fused;
 };
-void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, int parity, const HeadsPair &heads);
+void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, int parity, const HeadsPair &heads,
+                      const RoundDev *turnover = nullptr);
 hipError_t prepare_tree_fused(size_t lds_bytes);
 hipError_t prepare_tree_step();
 void launch_tree_fused(hipStream_t st, const EngineDev &e, const SearchDev &p, size_t lds_bytes);

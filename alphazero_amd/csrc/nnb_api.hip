@@ -290,9 +290,9 @@ StepPlan make_step_plan(nnb_engine *e, const nnb_search_params &p, const SearchD
 // One lock-step round: the tree step of every live game, then (unless it is the closing step of a
 // move) the evaluation of the leaves it batched.
 void lockstep_step(nnb_engine *e, hipStream_t st, const nnb_search_params &p, const SearchDev &sd, const StepPlan &plan,
-                   int parity, bool evaluate) {
+                   int parity, bool evaluate, const RoundDev *turnover = nullptr) {
     const EngineDev &d = e->dev;
-    { ProfScope ps(e, 0, st); launch_tree_step(st, d, sd, parity, plan.heads); }
+    { ProfScope ps(e, 0, st); launch_tree_step(st, d, sd, parity, plan.heads, turnover); }
     if (!evaluate) return;
     for (int b = 0; b < plan.nbatch; ++b) {
         if (p.evaluator == NNB_EVAL_NET) forward_leaves(e, st, sd.wset[b], b, parity, d.n_games, !plan.heads.fused);
@@ -568,8 +568,9 @@ int nnb_selfplay_round(nnb_engine *e, void *stream, const nnb_search_params *par
         const long long max_steps = ((long long)n_games / (slots > 0 ? slots : 1) + 2) * (kMaxPlies + 1) * (params->sims + 1);
         while (live > 0 && steps < max_steps) {
             for (int k = 0; k < kChunk; ++k, ++steps) {
-                launch_turnover(st, e->dev, sd, round, make_noise);
-                lockstep_step(e, st, *params, sd, plan, (int)(steps & 1), true);
+                // with root noise to draw the turnover is a launch of its own, otherwise part of the step
+                if (make_noise) launch_turnover(st, e->dev, sd, round, make_noise);
+                lockstep_step(e, st, *params, sd, plan, (int)(steps & 1), true, make_noise ? nullptr : &round);
             }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(e->host_counters, e->dev.counters + kLive, sizeof(int32_t), hipMemcpyDeviceToHost, st));

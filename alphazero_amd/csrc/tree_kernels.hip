@@ -414,8 +414,17 @@ constexpr int kTerminalSimsPerStep = 3;
 // game, from the linear layer's output - no separate heads launch, no round trip of values and
 // priors through memory.  The head rows the block needs are staged in LDS first (the value row
 // only under the reference rule, which ignores priors; all 8 rows under PUCT; per batch).
-template <bool AZ, bool HEADS>
-__global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e, SearchDev p, int parity, HeadsPair hp) {
+__device__ void readout_game(const EngineDev &e, const SearchDev &p, int g, int32_t *__restrict__ visits_out,
+                             int8_t *__restrict__ action_out, double *__restrict__ root_value_out,
+                             const RoundDev &round, int selfplay);
+
+// TURNOVER (self-play without a common move boundary, no device-drawn root noise): a game whose
+// simulation budget is used up ends its move here - readout, move, trajectory, retirement or the
+// next game of the round, fresh root - before the step carries on with its next search.  With
+// root noise to draw, turnover_kernel does the same ahead of the step instead.
+template <bool AZ, bool HEADS, bool TURNOVER>
+__global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e, SearchDev p, int parity, HeadsPair hp,
+                                                                    RoundDev round) {
     __shared__ int s_want[kStepGames];       // 0 = no leaf, 1 + batch otherwise
     __shared__ int s_base[2];
     extern __shared__ __attribute__((aligned(16))) float4 s_hw[];      // [batches][HROWS][256]
@@ -431,7 +440,17 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
         __syncthreads();
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { e.leaf_count[2 * (parity ^ 1)] = 0; e.leaf_count[2 * (parity ^ 1) + 1] = 0; }
-    const bool live = g < e.n_games && e.active[g];
+    bool live = g < e.n_games && e.active[g];
+    if constexpr (TURNOVER) {
+        if (live && e.pending[g] < 0 && e.sims_done[g] >= p.sims) {
+            if (lane == 0) {
+                readout_game(e, p, g, nullptr, nullptr, nullptr, round, 1);
+                if (e.active[g]) init_search(e, p, g, 0, 1);
+            }
+            wave_mem_sync();
+            live = e.active[g];
+        }
+    }
     const bool two_batches = p.wset[0] != p.wset[1];
     int batch = 0;
     // leaf found by this wave (if any), kept in registers until the block has claimed its
@@ -857,16 +876,26 @@ void launch_tree_init(hipStream_t st, const EngineDev &e, const SearchDev &p, in
     tree_init_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, p, make_noise, selfplay);
 }
 
-void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, int parity, const HeadsPair &heads) {
+template <bool AZ, bool HEADS>
+static void launch_tree_step_t(hipStream_t st, const EngineDev &e, const SearchDev &p, int parity, const HeadsPair &heads,
+                               const RoundDev *turnover, size_t lds) {
     const int blocks = cdiv(e.n_games, kStepGames), threads = kStepGames * 64;
+    const RoundDev none = {nullptr, nullptr, nullptr, 0, 0};
+    if (turnover) tree_step_kernel<AZ, HEADS, true><<<blocks, threads, lds, st>>>(e, p, parity, heads, *turnover);
+    else tree_step_kernel<AZ, HEADS, false><<<blocks, threads, lds, st>>>(e, p, parity, heads, none);
+}
+
+// turnover != null: games whose budget is used up end their move inside the step (see TURNOVER)
+void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, int parity, const HeadsPair &heads,
+                      const RoundDev *turnover) {
     const bool az = p.mode == NNB_MODE_AZ;
     if (heads.fused) {
         const size_t lds = (size_t)(p.wset[0] != p.wset[1] ? 2 : 1) * (az ? 8 : 1) * 4096;
-        if (az) tree_step_kernel<true, true><<<blocks, threads, lds, st>>>(e, p, parity, heads);
-        else tree_step_kernel<false, true><<<blocks, threads, lds, st>>>(e, p, parity, heads);
+        if (az) launch_tree_step_t<true, true>(st, e, p, parity, heads, turnover, lds);
+        else launch_tree_step_t<false, true>(st, e, p, parity, heads, turnover, lds);
     } else {
-        if (az) tree_step_kernel<true, false><<<blocks, threads, 0, st>>>(e, p, parity, heads);
-        else tree_step_kernel<false, false><<<blocks, threads, 0, st>>>(e, p, parity, heads);
+        if (az) launch_tree_step_t<true, false>(st, e, p, parity, heads, turnover, 0);
+        else launch_tree_step_t<false, false>(st, e, p, parity, heads, turnover, 0);
     }
 }
 
@@ -880,7 +909,10 @@ hipError_t prepare_tree_fused(size_t lds_bytes) {
 
 // The PUCT step kernel of a two-network arena stages 2 x 8 head rows = 64 KB of dynamic LDS.
 hipError_t prepare_tree_step() {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(tree_step_kernel<true, true>),
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(tree_step_kernel<true, true, false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4096);
+    if (err != hipSuccess) return err;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(tree_step_kernel<true, true, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4096);
 }
 
