@@ -525,21 +525,18 @@ constexpr size_t conv_rows_lds_bytes(int ih, int iw, int nb) {
 // ---------------------------------------------------------------------------
 constexpr int FCH_K = 11520, FCH_N = 1024, FCH_BM = 128, FCH_BN = 256, FCH_BK = 64, FCH_SPLIT = 2;
 
-// ABLATE (timing experiments only): 1 no A global loads, 2 no A-fragment LDS reads, 4 no weight loads.
-template <int ABLATE = 0, int BR = 8, int NSET = 2>
-__global__ __launch_bounds__(256, 1) void fc_f16_kernel(const _Float16 *__restrict__ a,   // [rows][11520]
-                                                        const _Float16 *__restrict__ wp,  // repacked
-                                                        float *__restrict__ part,         // [2][max_rows][1024]
-                                                        const int32_t *__restrict__ count_ptr, int n_fixed,
-                                                        int max_rows) {
-    __shared__ __attribute__((aligned(16))) uint4 lds[3][FCH_BM * 8];      // 128 rows x 64 halfs, three buffers
-    const int count = batch_count16(count_ptr, n_fixed);
+// MTR = 32-row tiles per block (1..4): the kernel picks the smallest that covers the batch with the
+// launched blocks, so a partly filled batch costs proportionally less instead of leaving CUs idle.
+template <int MTR, int ABLATE, int BR, int NSET>
+__device__ __forceinline__ void fc_f16_tile(const _Float16 *__restrict__ a, const _Float16 *__restrict__ wp,
+                                            float *__restrict__ part, int count, int max_rows,
+                                            uint4 (&lds)[3][FCH_BM * 8]) {
     const int bid = blockIdx.x;
     const int x = bid & 7, i = bid >> 3;                    // i in [0, 32 * groups)
     const int grp = i >> 5, ii = i & 31;
     const int mb = (grp * 8 + x) * 4 + (ii & 3);
     const int nb = (ii >> 2) & 3, ksp = ii >> 4;
-    const int row0 = mb * FCH_BM;
+    const int row0 = mb * (32 * MTR);
     if (row0 >= count) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, m = lane & 31, h = lane >> 5;
 #ifdef NNB_CONV_BENCH_CLOCKS
@@ -563,12 +560,12 @@ __global__ __launch_bounds__(256, 1) void fc_f16_kernel(const _Float16 *__restri
         int r = min(row0 + srow, max_rows - 1);                                                   \
         abase##C = reinterpret_cast<const uint4 *>(a + (size_t)r * FCH_K + k0) + scol;            \
     }
-    FC_MAP(0) FC_MAP(1) FC_MAP(2) FC_MAP(3)
+    FC_MAP(0) FC_MAP(1) FC_MAP(2) FC_MAP(3)     // chunk C belongs to row tile C; tiles >= MTR are never touched
 #undef FC_MAP
-#define FC_LOAD(S, SLAB)                                                                          \
-    { S##0 = abase0[(SLAB) * 8]; S##1 = abase1[(SLAB) * 8]; S##2 = abase2[(SLAB) * 8]; S##3 = abase3[(SLAB) * 8]; }
-#define FC_WRITE(S, BUF)                                                                          \
-    { lds[BUF][sdst0] = S##0; lds[BUF][sdst1] = S##1; lds[BUF][sdst2] = S##2; lds[BUF][sdst3] = S##3; }
+#define FC_LD1(S, C, SLAB) if constexpr ((C) < MTR) S##C = abase##C[(SLAB) * 8];
+#define FC_WR1(S, C, BUF) if constexpr ((C) < MTR) lds[BUF][sdst##C] = S##C;
+#define FC_LOAD(S, SLAB) { FC_LD1(S, 0, SLAB) FC_LD1(S, 1, SLAB) FC_LD1(S, 2, SLAB) FC_LD1(S, 3, SLAB) }
+#define FC_WRITE(S, BUF) { FC_WR1(S, 0, BUF) FC_WR1(S, 1, BUF) FC_WR1(S, 2, BUF) FC_WR1(S, 3, BUF) }
     // A-fragment read offsets (16-byte units) inside a buffer, per row tile, for k-step 0 of a slab
     int aoff[4], asw[4];
 #pragma unroll
@@ -605,16 +602,16 @@ __global__ __launch_bounds__(256, 1) void fc_f16_kernel(const _Float16 *__restri
     for (int j = 0; j < BR - 1; ++j) { br0[j] = wlane[(size_t)j * 2 * FCH_N]; br1[j] = wlane[(size_t)j * 2 * FCH_N + 32]; }
     uint4 afa[4], afb[4];                                   // A fragments of even / odd k-steps
 #pragma unroll
-    for (int t = 0; t < 4; ++t) afa[t] = lds[0][aoff[t] + (h ^ asw[t])];
+    for (int t = 0; t < MTR; ++t) afa[t] = lds[0][aoff[t] + (h ^ asw[t])];
 
 // one k-step: J = k-step index inside the 24-step body, KS = k-step inside its slab,
 // CUR / NXT = fragment sets (afa, afb), NBUF = LDS buffer the next step's fragments come from.
 // Each of the 8 MFMAs is followed by ONE memory instruction - two weight loads, the four
 // fragment reads of the next k-step, then two slots X0 / X1 that the slab macro fills with
 // staging work - and a scheduling fence, so the MFMA pipe never waits behind a run of loads.
-#define FC_MM(T, U_, CUR) acc[T][U_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(((ABLATE & 2) ? afa : CUR)[T]), U_ ? b1 : b0, acc[T][U_], 0, 0, 0);
+#define FC_MM(T, U_, CUR) if constexpr ((T) < MTR) acc[T][U_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(((ABLATE & 2) ? afa : CUR)[T]), U_ ? b1 : b0, acc[T][U_], 0, 0, 0);
 #define FC_RD(T, KS, NXT, NBUF)                                                                           \
-    if (((KS) < 3 || s + 1 < NSLAB) && !(ABLATE & 2)) NXT[T] = lds[NBUF][aoff[T] + ((2 * (((KS) + 1) & 3) + h) ^ asw[T])];
+    if constexpr ((T) < MTR) if (((KS) < 3 || s + 1 < NSLAB) && !(ABLATE & 2)) NXT[T] = lds[NBUF][aoff[T] + ((2 * (((KS) + 1) & 3) + h) ^ asw[T])];
 #define FC_SB __builtin_amdgcn_sched_barrier(0);
 #define FC_KSTEP(J, KS, CUR, NXT, NBUF, X0, X1)                                                           \
     {                                                                                                     \
@@ -633,9 +630,9 @@ __global__ __launch_bounds__(256, 1) void fc_f16_kernel(const _Float16 *__restri
 
 // one slab: U = slab index inside the 6-slab body (LDS buffer U % 3), STG = staging register set.
 // Slab s+2 goes registers -> LDS during k-steps 0 and 1, slab s+2+NSET global -> registers during 2 and 3.
-#define FC_W2(STG, BUF, A, B) if (s + 2 < NSLAB && !(ABLATE & 16)) { lds[BUF][sdst##A] = STG##A; lds[BUF][sdst##B] = STG##B; }
+#define FC_W2(STG, BUF, A, B) if (s + 2 < NSLAB && !(ABLATE & 16)) { FC_WR1(STG, A, BUF) FC_WR1(STG, B, BUF) }
 #define FC_L2(STG, A, B)                                                                                  \
-    if (s + 2 + NSET < NSLAB && !(ABLATE & 1)) { STG##A = abase##A[(s + 2 + NSET) * 8]; STG##B = abase##B[(s + 2 + NSET) * 8]; }
+    if (s + 2 + NSET < NSLAB && !(ABLATE & 1)) { FC_LD1(STG, A, s + 2 + NSET) FC_LD1(STG, B, s + 2 + NSET) }
 #define FC_SLAB(U, STG)                                                                                   \
     {                                                                                                     \
         const int s = s6 + (U);                                                                           \
@@ -663,10 +660,12 @@ __global__ __launch_bounds__(256, 1) void fc_f16_kernel(const _Float16 *__restri
 #undef FC_L2
 #undef FC_LOAD
 #undef FC_WRITE
+#undef FC_LD1
+#undef FC_WR1
 
     float *obase = part + (size_t)ksp * max_rows * FCH_N + nb * FCH_BN + w * 64 + m;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < MTR; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int row = row0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -676,6 +675,24 @@ __global__ __launch_bounds__(256, 1) void fc_f16_kernel(const _Float16 *__restri
             }
         }
     }
+}
+
+// ABLATE (timing experiments only): 1 no A global loads, 2 no A-fragment LDS reads, 4 no weight loads,
+// 8 no barriers, 16 no staging writes.
+template <int ABLATE = 0, int BR = 8, int NSET = 2>
+__global__ __launch_bounds__(256, 1) void fc_f16_kernel(const _Float16 *__restrict__ a,   // [rows][11520]
+                                                        const _Float16 *__restrict__ wp,  // repacked
+                                                        float *__restrict__ part,         // [2][max_rows][1024]
+                                                        const int32_t *__restrict__ count_ptr, int n_fixed,
+                                                        int max_rows) {
+    __shared__ __attribute__((aligned(16))) uint4 lds[3][FCH_BM * 8];      // 128 rows x 64 halfs, three buffers
+    const int count = batch_count16(count_ptr, n_fixed);
+    const int mblocks = gridDim.x >> 3;                     // row blocks the grid provides (8 column/K blocks each)
+    const int tiles = (count + 32 * mblocks - 1) / (32 * mblocks);
+    if (tiles <= 1) fc_f16_tile<1, ABLATE, BR, NSET>(a, wp, part, count, max_rows, lds);
+    else if (tiles == 2) fc_f16_tile<2, ABLATE, BR, NSET>(a, wp, part, count, max_rows, lds);
+    else if (tiles == 3) fc_f16_tile<3, ABLATE, BR, NSET>(a, wp, part, count, max_rows, lds);
+    else fc_f16_tile<4, ABLATE, BR, NSET>(a, wp, part, count, max_rows, lds);
 }
 
 // ---------------------------------------------------------------------------
