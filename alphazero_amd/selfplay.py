@@ -43,6 +43,28 @@ def gather_trajectories(local: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
+def random_openings(engine, num_games: int, plies: int, seed: int = 0):
+    """Start positions after `plies` uniformly random legal moves from the empty board (moves applied on
+    the device with the engine's rule kernel).  The reference search is deterministic, so without this
+    every self-play game from the empty board is the same game.  Returns (colour boards uint64[n,2],
+    movers int8[n]); at most 6 plies, so no start position is finished."""
+    if not 0 <= plies <= 6:
+        raise ValueError("plies must be in [0, 6]")
+    rng = np.random.RandomState(seed)
+    boards = np.zeros((num_games, 2), dtype=np.uint64)
+    player = 1
+    for _ in range(plies):
+        _, legal, _ = engine.game_ops(boards)
+        pick = rng.randint(0, 1 << 30, size=num_games)
+        cols = np.zeros(num_games, dtype=np.int8)
+        for i in range(num_games):
+            open_cols = [c for c in range(7) if (int(legal[i]) >> c) & 1]
+            cols[i] = open_cols[pick[i] % len(open_cols)]
+        boards, _, _ = engine.game_ops(boards, np.full(num_games, player, dtype=np.int8), cols)
+        player = 3 - player
+    return boards, np.full(num_games, player, dtype=np.int8)
+
+
 def play_games(agent, num_games: int, first_game_id: int = 0, start_boards=None, start_players=None):
     """Plays `num_games` games on the agent's engine; returns (records, stats) where records is a
     structured numpy array (engine.TRAJECTORY_DTYPE) and stats sums the engine's round statistics."""

@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--sims", type=int, default=SIMS)
     ap.add_argument("--precision", choices=["f16", "f32"], default="f16",
                     help="arithmetic of the network's conv / linear layers (both accumulate in f32)")
+    ap.add_argument("--opening-plies", type=int, default=0,
+                    help="random legal moves played before self-play starts (0 = every game from the empty board, as the\n"
+                         "reference plays; its search is deterministic, so those games are all the same game)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -120,8 +123,14 @@ def main():
     traj = torch.empty((G, TRAJECTORY_BYTES), dtype=torch.uint8, device=device)
     replay = torch.empty((world * G, TRAJECTORY_BYTES), dtype=torch.uint8, device=device) if use_dist else traj
 
+    start_boards = start_players = None
+    if args.opening_plies > 0:
+        from alphazero_amd.selfplay import random_openings
+        start_boards, start_players = random_openings(engine, G, args.opening_plies, seed=1234 + rank)
+
     def one_round(step_idx: int):
-        _, stats = engine.selfplay_round(G, params, first_game_id=(step_idx * world + rank) * G, out=traj)
+        _, stats = engine.selfplay_round(G, params, first_game_id=(step_idx * world + rank) * G, out=traj,
+                                         start_boards=start_boards, start_players=start_players)
         if use_dist:
             dist.all_gather_into_tensor(replay, traj)      # RCCL: trajectories into every rank's buffer
         return stats
@@ -210,7 +219,8 @@ def main():
             "dtype": DTYPE_NAME[args.precision],
             "data": "synthetic: games from the empty board, random-init Connect4Net (torch.manual_seed(0))",
             "config": {"workload": f"{G} concurrent games per GPU x {args.sims} sims/move, batched leaf inference, "
-                                   "reference search rule (compat), every game played to the end",
+                                   "reference search rule (compat), every game played to the end"
+                                   + (f", {args.opening_plies} random opening plies" if args.opening_plies else ""),
                        "games_per_gpu": G, "sims_per_move": args.sims, "c_puct": C_PUCT,
                        "parallelism": f"games sharded over {world} GPU(s), no collective inside the search; "
                                       "one all-gather of trajectories per round"},

@@ -157,3 +157,27 @@ def test_games_without_a_common_move_boundary_equal_synchronised_moves(gpu, orac
         assert out[0][1]["steps"] < out[1][1]["steps"]        # fewer lock-step rounds for the same games
     finally:
         eng.close()
+
+
+def test_random_openings_are_legal_positions(gpu, oracle):
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.selfplay import random_openings
+    co, _ = oracle
+    eng = Engine(max_games=8, max_sims=8)
+    try:
+        for plies in (0, 3, 6):
+            boards, movers = random_openings(eng, 300, plies, seed=4)
+            again, _ = random_openings(eng, 300, plies, seed=4)
+            assert (boards == again).all()
+            assert (movers == 1 + plies % 2).all()
+            for b1, b2 in boards[:100]:
+                b1, b2 = int(b1), int(b2)
+                assert b1 & b2 == 0 and bin(b1).count("1") == (plies + 1) // 2 and bin(b2).count("1") == plies // 2
+                assert not co.lib().orc_is_terminal(b1, b2)
+                for c in range(7):                      # no stone in mid-air
+                    col = ((b1 | b2) >> (7 * c)) & 0x3F
+                    assert col & (col + 1) == 0
+            if plies:
+                assert len({(int(a), int(b)) for a, b in boards}) > 20
+    finally:
+        eng.close()

@@ -3,9 +3,10 @@
   tree     pure-tree search, PUCT with uniform priors + bitboard random rollouts, 800 sims/move
            (whole move in one launch, node pool in LDS); also the reference rule with the same evaluator
   az       PUCT + Dirichlet root noise with the network, 4096 games x 200 sims/move
+  diverse  the reference rule with the network, 4 random opening plies, 4 x as many games as slots
   arena    two networks against each other, 400 sims/move, starter alternates, both nets batched
 
-  python tools/bench_configs.py [tree az arena] [--games N]
+  python tools/bench_configs.py [tree az diverse arena] [--games N]
 
 Prints one JSON line per workload.  Inputs are resident on the device before the clock starts.
 """
@@ -50,7 +51,7 @@ def report(name, dt, st, extra=None):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", nargs="*", default=["tree", "az", "arena"])
+    ap.add_argument("what", nargs="*", default=["tree", "az", "diverse", "arena"])
     ap.add_argument("--games", type=int, default=4096)
     ap.add_argument("--arena-games", type=int, default=10000)
     a = ap.parse_args()
@@ -75,6 +76,22 @@ def main():
                               "net_leaves": st["net_leaves"], "terminal_hits": st["terminal_hits"]}))
             report(f"az: {total} games on {G} slots x 200 sims/move, PUCT + Dirichlet(0.3, eps 0.25), network", dt, st,
                    {"leaf_batch_fill": st["net_leaves"] / max(st["steps"] * G, 1)})
+        eng.close()
+    if "diverse" in a.what:
+        from alphazero_amd.selfplay import random_openings
+        eng = Engine(max_games=G, max_sims=200)
+        eng.load_state_dict(seeded_state_dict(0))
+        p = eng.params(200, 1.4, evaluator="net", mode="compat")
+        total = 4 * G
+        sb, sp = random_openings(eng, total, 4, seed=1)
+        eng.selfplay_round(256, p)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        traj, st = eng.selfplay_round(total, p, start_boards=sb, start_players=sp)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        report(f"diverse: {total} games on {G} slots x 200 sims/move, reference rule, 4 random opening plies, network", dt, st,
+               {"leaf_batch_fill": st["net_leaves"] / max(st["steps"] * G, 1)})
         eng.close()
     if "arena" in a.what:
         eng = Engine(max_games=G, max_sims=400, n_weight_sets=2)
