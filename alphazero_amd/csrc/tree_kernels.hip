@@ -410,14 +410,15 @@ constexpr int kStepGames = 16;                    // games (wavefronts) per bloc
 // order of a game's simulations is unchanged, so results are too; S+1 steps still suffice.
 constexpr int kTerminalSimsPerStep = 3;
 
-// HEADS: the network's heads for the pending leaf are computed here, by the wave that owns the
-// game, from the linear layer's output - no separate heads launch, no round trip of values and
-// priors through memory.  The head rows the block needs are staged in LDS first (the value row
-// only under the reference rule, which ignores priors; all 8 rows under PUCT; per batch).
 __device__ void readout_game(const EngineDev &e, const SearchDev &p, int g, int32_t *__restrict__ visits_out,
                              int8_t *__restrict__ action_out, double *__restrict__ root_value_out,
                              const RoundDev &round, int selfplay);
 
+// HEADS: the network's heads for the pending leaf are computed here, by the wave that owns the
+// game, from the linear layer's output - no separate heads launch, no round trip of values and
+// priors through memory.  The head rows the block needs are staged in LDS first (the value row
+// only under the reference rule, which ignores priors; all 8 rows under PUCT; per batch).
+//
 // TURNOVER (self-play without a common move boundary, no device-drawn root noise): a game whose
 // simulation budget is used up ends its move here - readout, move, trajectory, retirement or the
 // next game of the round, fresh root - before the step carries on with its next search.  With

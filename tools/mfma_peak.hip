@@ -7,6 +7,7 @@
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
+typedef float float4v __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void spin(int iters, float *out, unsigned long long *clk) {
     half8 a, b;
@@ -22,6 +23,24 @@ __global__ __launch_bounds__(256) void spin(int iters, float *out, unsigned long
     unsigned long long t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
     float s = 0;
     for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
+}
+
+// same FLOPs per iteration with the 16x16x32 instruction (16 accumulators of 4 registers)
+__global__ __launch_bounds__(256) void spin16(int iters, float *out, unsigned long long *clk) {
+    half8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(0.5f + i); }
+    float4v c[8];
+    for (int j = 0; j < 8; ++j) c[j] = float4v{0, 0, 0, 0};
+    unsigned long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c[j], 0, 0, 0);
+    }
+    unsigned long long t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    float s = 0;
+    for (int j = 0; j < 8; ++j) s += c[j][0] + c[j][1] + c[j][2] + c[j][3];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
 }
@@ -42,6 +61,27 @@ int main() {
         double flop = (double)blocks * 4 * iters * 4 * 32768.0;
         printf("rep %d: %.3f ms  %.1f TFLOP/s  shader ticks %llu  wall ticks (100 MHz) %llu -> %.0f MHz\n", rep, ms,
                flop / (ms * 1e-3) / 1e12, h[0], h[1], (double)h[0] / (double)h[1] * 100.0);
+    }
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        spin16<<<blocks, 256>>>(iters, out, clk);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+        double flop = (double)blocks * 4 * iters * 8 * 16384.0;
+        printf("16x16x32 rep %d: %.3f ms  %.1f TFLOP/s  shader ticks %llu  wall ticks %llu -> %.0f MHz\n", rep, ms,
+               flop / (ms * 1e-3) / 1e12, h[0], h[1], (double)h[0] / (double)h[1] * 100.0);
+    }
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        spin<<<blocks, 256>>>(iters, out, clk);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+        double flop = (double)blocks * 4 * iters * 4 * 32768.0;
+        printf("32x32x16 again rep %d: %.3f ms  %.1f TFLOP/s -> %.0f MHz\n", rep, ms, flop / (ms * 1e-3) / 1e12, (double)h[0] / (double)h[1] * 100.0);
     }
     return 0;
 }
