@@ -57,6 +57,7 @@ SIGNATURES = {
     "nnb_load_weights": (C.c_int, [_P, C.c_int, _P] + [_P] * 12),
     "nnb_game_ops": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "nnb_encode_planes": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "nnb_minimax": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P]),
     "nnb_ucb_scores": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_double, _P]),
     "nnb_net_forward": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P, _P, _P, _P, _P]),
     "nnb_net_forward_planes": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P, _P, _P]),

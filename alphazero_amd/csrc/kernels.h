@@ -10,6 +10,8 @@ namespace nnb {
 void launch_game_ops(hipStream_t st, int n, const u64 *in, const int8_t *players, const int8_t *actions,
                      u64 *out, uint8_t *legal_out, uint8_t *status_out);
 void launch_encode_planes(hipStream_t st, int n, const u64 *side, float *planes);
+void launch_minimax(hipStream_t st, int n, const u64 *boards, const int8_t *movers, int depth, int8_t *col_out,
+                    int32_t *score_out);
 void launch_ucb_scores(hipStream_t st, int n, const double *value, const int32_t *visits,
                        const int32_t *parent_visits, double c_puct, const double *log_table, int log_n,
                        double *out);

@@ -457,6 +457,18 @@ int nnb_game_ops(void *stream, int32_t n, const uint64_t *in, const int8_t *play
     return NNB_OK;
 }
 
+int nnb_minimax(void *stream, int32_t n, const uint64_t *colour_boards, const int8_t *movers, int32_t depth,
+                int8_t *column_out, int32_t *score_out) {
+    if (n < 0) return fail(NNB_ERR_ARG, "n < 0");
+    if (n == 0) return NNB_OK;
+    if (!colour_boards || !movers) return fail(NNB_ERR_ARG, "null pointer");
+    if (depth < 0 || depth > 8) return fail(NNB_ERR_ARG, "depth %d out of range [0, 8]", depth);
+    launch_minimax(static_cast<hipStream_t>(stream), n, reinterpret_cast<const u64 *>(colour_boards), movers, depth,
+                   column_out, score_out);
+    HIP_TRY(hipGetLastError());
+    return NNB_OK;
+}
+
 int nnb_encode_planes(void *stream, int32_t n, const uint64_t *side_boards, float *planes_out) {
     if (n < 0) return fail(NNB_ERR_ARG, "n < 0");
     if (n == 0) return NNB_OK;

@@ -850,6 +850,137 @@ __global__ void fixed_eval_kernel(EngineDev e, SearchDev p, int batch, int parit
 }
 
 // ---------------------------------------------------------------------------
+// Depth-limited minimax opponent (nnbattle/agents/minimax/agent_code.py:34-89) with the position
+// score of connect_four_game.py:215-278.  The maximising side is the side to move (the reference
+// always maximises for colour 2; the two agree whenever colour 2 moves).  Alpha-beta only prunes,
+// it never changes the root's choice, so the tree is searched exhaustively here: one wavefront per
+// position, lane 7*c1 + c2 owns the subtree behind the first two plies (c1, c2), the wave reduces
+// min over c2 then max over c1, lowest column on ties (the reference keeps the first maximum).
+// ---------------------------------------------------------------------------
+constexpr int kMinimaxInf = 1 << 30;
+constexpr int kMinimaxMaxDepth = 8;
+
+struct WindowTable { u64 m[69]; };
+__host__ __device__ constexpr u64 window_mask(int r0, int c0, int dr, int dc) {    // rows counted from the top
+    u64 m = 0;
+    for (int i = 0; i < 4; ++i) m |= 1ULL << ((c0 + dc * i) * 7 + (5 - (r0 + dr * i)));
+    return m;
+}
+__host__ __device__ constexpr WindowTable make_windows() {
+    WindowTable t{};
+    int n = 0;
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 4; ++c) t.m[n++] = window_mask(r, c, 0, 1);
+    for (int c = 0; c < 7; ++c) for (int r = 0; r < 3; ++r) t.m[n++] = window_mask(r, c, 1, 0);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) t.m[n++] = window_mask(r, c, 1, 1);
+    for (int r = 3; r < 6; ++r) for (int c = 0; c < 4; ++c) t.m[n++] = window_mask(r, c, -1, 1);
+    return t;
+}
+__constant__ WindowTable c_windows = make_windows();
+
+// score_position / evaluate_window (connect_four_game.py:215-278) for the side owning `me`
+__device__ int score_position(u64 me, u64 opp) {
+    const u64 empty = ~(me | opp);
+    int score = 3 * __popcll(me & (0x3FULL << 21));
+    for (int i = 0; i < 69; ++i) {
+        const u64 w = c_windows.m[i];
+        const int a = __popcll(me & w), o = __popcll(opp & w), e = __popcll(empty & w);
+        score += a == 4 ? 100 : (a == 3 && e == 1) ? 5 : (a == 2 && e == 2) ? 2 : 0;
+        score -= (o == 3 && e == 1) ? 4 : 0;
+    }
+    return score;
+}
+
+// Exhaustive minimax value of (mine, theirs) for the maximising side `mine`; `my_turn` = the
+// maximising side is to move.  Iterative depth-first walk, `depth` plies deep.
+__device__ int minimax_value(u64 mine, u64 theirs, bool my_turn, int depth) {
+    u64 sm[kMinimaxMaxDepth + 1], st[kMinimaxMaxDepth + 1];
+    int val[kMinimaxMaxDepth + 1], col[kMinimaxMaxDepth + 1];
+    int L = 0;
+    sm[0] = mine; st[0] = theirs; col[0] = -1;
+    int ret = 0;
+    bool have_ret = false;
+    while (true) {
+        const bool maxi = (L & 1) ? !my_turn : my_turn;
+        if (col[L] < 0) {                                   // first visit of this node
+            if (c4::has_four(sm[L])) { ret = kMinimaxInf; have_ret = true; }
+            else if (c4::has_four(st[L])) { ret = -kMinimaxInf; have_ret = true; }
+            else if (c4::legal_mask(sm[L] | st[L]) == 0) { ret = 0; have_ret = true; }
+            else if (L == depth) { ret = score_position(sm[L], st[L]); have_ret = true; }
+            else { val[L] = maxi ? -kMinimaxInf - 1 : kMinimaxInf + 1; col[L] = 0; }
+        }
+        if (!have_ret) {
+            const unsigned legal = c4::legal_mask(sm[L] | st[L]);
+            int c = col[L];
+            while (c < 7 && !((legal >> c) & 1)) ++c;
+            if (c >= 7) { ret = val[L]; have_ret = true; }
+            else {
+                col[L] = c + 1;
+                const u64 cell = c4::drop_cell(sm[L] | st[L], c);
+                sm[L + 1] = maxi ? sm[L] | cell : sm[L];
+                st[L + 1] = maxi ? st[L] : st[L] | cell;
+                col[L + 1] = -1;
+                ++L;
+                continue;
+            }
+        }
+        // hand `ret` to the parent
+        if (L == 0) return ret;
+        --L;
+        have_ret = false;
+        const bool pmax = (L & 1) ? !my_turn : my_turn;
+        val[L] = pmax ? (ret > val[L] ? ret : val[L]) : (ret < val[L] ? ret : val[L]);
+    }
+}
+
+__global__ __launch_bounds__(64) void minimax_kernel(int n, const u64 *__restrict__ boards,
+                                                     const int8_t *__restrict__ movers, int depth,
+                                                     int8_t *__restrict__ col_out, int32_t *__restrict__ score_out) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= n) return;
+    const u64 b1 = boards[2 * g] & c4::kBoardMask, b2 = boards[2 * g + 1] & c4::kBoardMask & ~b1;
+    const bool two = movers[g] == 2;
+    const u64 mine = two ? b2 : b1, theirs = two ? b1 : b2;
+    const unsigned legal = c4::legal_mask(mine | theirs);
+    int root_col = -1, root_val;
+    if (c4::has_four(mine)) root_val = kMinimaxInf;
+    else if (c4::has_four(theirs)) root_val = -kMinimaxInf;
+    else if (legal == 0) root_val = 0;
+    else if (depth == 0) root_val = score_position(mine, theirs);
+    else {
+        // lane -> (c1, c2); value of the position behind those plies from the maximiser's side
+        const int c1 = lane / 7, c2 = lane % 7;
+        int v = kMinimaxInf + 1;                             // neutral for the min over c2
+        bool c1_final = false;                               // c1 ends the search (win, full board, horizon)
+        int v1_direct = 0;
+        if (lane < 49 && ((legal >> c1) & 1)) {
+            const u64 m1 = mine | c4::drop_cell(mine | theirs, c1);
+            const unsigned legal1 = c4::legal_mask(m1 | theirs);
+            if (c4::has_four(m1)) { c1_final = true; v1_direct = kMinimaxInf; }
+            else if (legal1 == 0) { c1_final = true; v1_direct = 0; }
+            else if (depth == 1) { c1_final = true; v1_direct = score_position(m1, theirs); }
+            else if ((legal1 >> c2) & 1) {
+                const u64 t2 = theirs | c4::drop_cell(m1 | theirs, c2);
+                v = minimax_value(m1, t2, true, depth - 2);
+            }
+        }
+        // min over c2 inside each group of 7 lanes, then max over c1 (lowest column wins ties)
+        int best = -kMinimaxInf - 2;
+        for (int k = 0; k < 7; ++k) {
+            int vk = kMinimaxInf + 1;
+            for (int j = 0; j < 7; ++j) { const int x = __shfl(v, 7 * k + j); vk = x < vk ? x : vk; }
+            const int fin = __shfl((int)c1_final, 7 * k), dir = __shfl(v1_direct, 7 * k);
+            if (fin) vk = dir;
+            if (((legal >> k) & 1) && vk > best) { best = vk; root_col = k; }
+        }
+        root_val = best;
+    }
+    if (lane == 0) {
+        if (col_out) col_out[g] = (int8_t)root_col;
+        if (score_out) score_out[g] = root_val;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Host launchers
 // ---------------------------------------------------------------------------
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -937,6 +1068,11 @@ void launch_readout(hipStream_t st, const EngineDev &e, const SearchDev &p, int3
 
 void launch_turnover(hipStream_t st, const EngineDev &e, const SearchDev &p, const RoundDev &round, int make_noise) {
     turnover_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, p, round, make_noise);
+}
+
+void launch_minimax(hipStream_t st, int n, const u64 *boards, const int8_t *movers, int depth, int8_t *col_out,
+                    int32_t *score_out) {
+    minimax_kernel<<<n, 64, 0, st>>>(n, boards, movers, depth, col_out, score_out);
 }
 
 void launch_selfplay_init(hipStream_t st, const EngineDev &e, const RoundDev &round) {

@@ -135,6 +135,19 @@ class Engine:
                                         _ptr(legal), _ptr(status)), "nnb_game_ops")
         return out.cpu().numpy().view(np.uint64), legal.cpu().numpy(), status.cpu().numpy()
 
+    def minimax(self, colour_boards, movers, depth: int):
+        """Depth-limited minimax move for the side to move of every position.
+        Returns (column int8[n] (-1 = none), root value int32[n]) as numpy arrays."""
+        b = self._dev(np.asarray(colour_boards, dtype=np.uint64).reshape(-1, 2), torch.int64)
+        n = b.shape[0]
+        mv = self._dev(np.asarray(movers, dtype=np.int8), torch.int8)
+        col = torch.empty(n, dtype=torch.int8, device=self.device)
+        score = torch.empty(n, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.nnb_minimax(self._stream(), n, _ptr(b), _ptr(mv), int(depth), _ptr(col), _ptr(score)),
+                  "nnb_minimax")
+        return col.cpu().numpy(), score.cpu().numpy()
+
     def encode_planes(self, side_boards) -> torch.Tensor:
         b = self._dev(np.asarray(side_boards, dtype=np.uint64).reshape(-1, 2), torch.int64)
         n = b.shape[0]

@@ -11,7 +11,8 @@ with an index appended when two agents share a class.
 Two engine-backed AlphaZeroAgents with the same search settings do not take turns on the
 host at all: `arena` plays every game of the tournament concurrently on one engine that
 holds both networks, each search's leaves batched with the other games' leaves that the
-same network judges (`run_tournament` takes that route by itself).
+same network judges (`run_tournament` takes that route by itself).  The reference's own pairing,
+MinimaxAgent against AlphaZeroAgent (run_tournament.py:44-48), is batched too (`mixed_arena`).
 """
 from __future__ import annotations
 
@@ -108,16 +109,86 @@ def arena(agents, num_games: int, engine=None, first_game_id: int = 0):
     return wins_a, wins_b, int(len(res) - wins_a - wins_b), records
 
 
+def mixed_arena_capable(agents) -> bool:
+    """True for the reference's own pairing (run_tournament.py:44-48): one MinimaxAgent and one
+    AlphaZeroAgent, in either order."""
+    from .agent import AlphaZeroAgent
+    from .minimax import MinimaxAgent
+    if len(agents) != 2:
+        return False
+    kinds = {type(a) for a in agents}
+    return kinds == {MinimaxAgent, AlphaZeroAgent} and all(
+        a.num_simulations >= 2 for a in agents if isinstance(a, AlphaZeroAgent))
+
+
+def mixed_arena(agents, num_games: int):
+    """AlphaZeroAgent against MinimaxAgent, all games of the tournament advanced together: at every
+    ply the positions where the minimax agent is to move go through one nnb_minimax call and those
+    where the AlphaZero agent is to move through batched searches; moves are applied with the rule
+    kernel.  Same protocol as `play_match` (agents[0] plays colour 1, game i is started by
+    agents[i % 2], a missing move counts as a draw); returns the list of winners, one of
+    0 (agents[0]), 1 (agents[1]) or None (draw) per game."""
+    from .agent import AlphaZeroAgent
+    if not mixed_arena_capable(agents):
+        raise ValueError("mixed_arena needs one MinimaxAgent and one AlphaZeroAgent")
+    az_seat = 0 if isinstance(agents[0], AlphaZeroAgent) else 1
+    az, mm = agents[az_seat], agents[1 - az_seat]
+    if az.load_model_flag and not az.model_loaded:
+        az.load_model()
+    n = int(num_games)
+    chunk = min(max(n, 1), ARENA_CONCURRENT_GAMES)
+    eng = az.engine(chunk)
+    params = eng.params(az.num_simulations, az.c_puct, evaluator=az.evaluator, mode="compat")
+    boards = np.zeros((n, 2), dtype=np.uint64)
+    seat = (np.arange(n) % 2).astype(np.int64)              # whose turn it is; seat s plays colour s + 1
+    live = np.ones(n, dtype=bool)
+    winners = [None] * n
+    for _ply in range(42):
+        if not live.any():
+            break
+        action = np.full(n, -1, dtype=np.int8)
+        idx = np.nonzero(live & (seat != az_seat))[0]
+        if len(idx):
+            col, _ = eng.minimax(boards[idx], (seat[idx] + 1).astype(np.int8), mm.depth)
+            action[idx] = col
+        idx = np.nonzero(live & (seat == az_seat))[0]
+        for lo in range(0, len(idx), chunk):
+            part = idx[lo:lo + chunk]
+            _, act, _, _ = eng.search(boards[part], (seat[part] + 1).astype(np.int8), params)
+            action[part] = act
+        live &= action >= 0                                  # no move available: the game counts as a draw
+        idx = np.nonzero(live)[0]
+        if not len(idx):
+            break
+        new, _legal, status = eng.game_ops(boards[idx], (seat[idx] + 1).astype(np.int8), action[idx])
+        boards[idx] = new
+        for k, i in enumerate(idx):
+            st = int(status[k])
+            if not st & 1:                                   # column was full: not a valid location
+                live[i] = False
+            elif st & 6:                                       # somebody has four: it is the mover
+                winners[i] = int(seat[i])
+                live[i] = False
+            elif st & 8:
+                live[i] = False
+        seat[idx] = 1 - seat[idx]
+    return winners
+
+
 def run_tournament(agents, num_games=100, results_dir=os.path.join("tournament", "results"), batched=None):
-    """run_tournament.py:12-42.  batched=None picks the engine arena when the pair allows it."""
+    """run_tournament.py:12-42.  batched=None picks a batched engine arena when the pair allows it."""
     names = _names(agents)
     results = {n: 0 for n in names}
     results["draws"] = 0
     if batched is None:
-        batched = arena_capable(agents)
-    if batched:
+        import torch
+        batched = arena_capable(agents) or (mixed_arena_capable(agents) and torch.cuda.is_available())
+    if batched and arena_capable(agents):
         wa, wb, dr, _ = arena(agents, num_games)
         results[names[0]], results[names[1]], results["draws"] = wa, wb, dr
+    elif batched and mixed_arena_capable(agents):
+        for w in mixed_arena(agents, num_games):
+            results["draws" if w is None else names[w]] += 1
     else:
         game = ConnectFourGame()
         for i in range(num_games):
@@ -130,4 +201,4 @@ def run_tournament(agents, num_games=100, results_dir=os.path.join("tournament",
     return results
 
 
-__all__ = ["run_tournament", "play_match", "arena", "arena_capable"]
+__all__ = ["run_tournament", "play_match", "arena", "arena_capable", "mixed_arena", "mixed_arena_capable"]

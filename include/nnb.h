@@ -210,6 +210,18 @@ int nnb_net_forward(nnb_engine *engine, int weight_set, void *stream, int32_t n,
 int nnb_net_forward_planes(nnb_engine *engine, int weight_set, void *stream, int32_t n,
                            const float *planes, float *log_policy_out, float *value_out);
 
+/* ---- baseline opponent ---------------------------------------------------- */
+/* MinimaxAgent.select_move (nnbattle/agents/minimax/agent_code.py:23-89, position score of
+ * connect_four_game.py:215-278) for n positions at once: depth-limited minimax, depth in [0, 8],
+ * for the side to move movers[i].  The reference agent maximises for colour 2 whoever moves; this
+ * one maximises for the mover, which is the same search whenever colour 2 is to move.
+ * column_out[i] = chosen column (lowest column among equally good ones; -1 in a finished position,
+ * without a legal move, or at depth 0); where the reference falls back to random.choice because
+ * every move loses inside the horizon, the lowest legal column is returned.  score_out[i] = root
+ * value, +-2^30 for a forced win / loss.  Either output may be NULL.  Asynchronous on `stream`. */
+int nnb_minimax(void *stream, int32_t n, const uint64_t *colour_boards, const int8_t *movers, int32_t depth,
+                int8_t *column_out, int32_t *score_out);
+
 /* ---- K2 + K7: search ----------------------------------------------------- */
 /* Runs one search per root position (AlphaZeroAgent.mcts_simulate,
  * agent_code.py:144-234) for n <= max_games independent roots, one wavefront per

@@ -410,3 +410,85 @@ int orc_az_search(u64 b1, u64 b2, int player, int sims, double c_puct, int eval_
     return best_a;
 }
 
+
+/* =======================================================================
+ * Depth-limited minimax opponent (nnbattle/agents/minimax/agent_code.py:34-89) with the
+ * position score of connect_four_game.py:215-278, on bitboards.
+ *
+ * The reference agent always maximises for AI_PIECE (= 2), whoever is to move; here the
+ * maximising side is the root mover, which is the same thing whenever colour 2 is to move
+ * (the case the golden vectors cover).  Win / loss are +-ORC_MM_INF (the reference's
+ * +-math.inf).  When every move loses inside the horizon the reference returns
+ * random.choice(valid_locations); this restatement returns the lowest legal column.
+ * ===================================================================== */
+#define ORC_MM_INF (1 << 30)
+
+static int mm_bit(int row_from_top, int col) { return col * 7 + (5 - row_from_top); }
+
+/* the 69 windows in the order of connect_four_game.py:228-254 (the order does not matter for a sum) */
+static int mm_windows(u64 *out) {
+    int n = 0;
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 4; ++c) { u64 m = 0; for (int i = 0; i < 4; ++i) m |= 1ULL << mm_bit(r, c + i); out[n++] = m; }
+    for (int c = 0; c < 7; ++c)
+        for (int r = 0; r < 3; ++r) { u64 m = 0; for (int i = 0; i < 4; ++i) m |= 1ULL << mm_bit(r + i, c); out[n++] = m; }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) { u64 m = 0; for (int i = 0; i < 4; ++i) m |= 1ULL << mm_bit(r + i, c + i); out[n++] = m; }
+    for (int r = 3; r < 6; ++r)
+        for (int c = 0; c < 4; ++c) { u64 m = 0; for (int i = 0; i < 4; ++i) m |= 1ULL << mm_bit(r - i, c + i); out[n++] = m; }
+    return n;
+}
+
+/* score_position(piece) with evaluate_window (connect_four_game.py:256-278) */
+int orc_score_position(u64 b1, u64 b2, int piece) {
+    static u64 win[69];
+    static int nwin = 0;
+    if (!nwin) nwin = mm_windows(win);
+    const u64 me = piece == 1 ? b1 : b2, opp = piece == 1 ? b2 : b1, empty = ~(b1 | b2);
+    int score = 3 * __builtin_popcountll(me & (0x3FULL << (3 * 7)));      /* centre column */
+    for (int i = 0; i < nwin; ++i) {
+        const int a = __builtin_popcountll(me & win[i]), o = __builtin_popcountll(opp & win[i]);
+        const int e = __builtin_popcountll(empty & win[i]);
+        if (a == 4) score += 100;
+        else if (a == 3 && e == 1) score += 5;
+        else if (a == 2 && e == 2) score += 2;
+        if (o == 3 && e == 1) score -= 4;
+    }
+    return score;
+}
+
+static int mm_search(u64 b1, u64 b2, int mover, int me, int depth, int alpha, int beta, int maximizing, int *col_out) {
+    const u64 mine = me == 1 ? b1 : b2, theirs = me == 1 ? b2 : b1;
+    *col_out = -1;
+    if (orc_has_four(mine)) return ORC_MM_INF;
+    if (orc_has_four(theirs)) return -ORC_MM_INF;
+    const int legal = orc_legal_mask(b1, b2);
+    if (!legal) return 0;
+    if (depth == 0) return orc_score_position(b1, b2, me);
+    int value = maximizing ? -ORC_MM_INF - 1 : ORC_MM_INF + 1;
+    for (int c = 0; c < ORC_COLS; ++c) {
+        if (!((legal >> c) & 1)) continue;
+        u64 c1 = b1, c2 = b2;
+        orc_drop(&c1, &c2, mover, c);
+        int sub;
+        const int s = mm_search(c1, c2, 3 - mover, me, depth - 1, alpha, beta, !maximizing, &sub);
+        if (maximizing) {
+            if (s > value) { value = s; *col_out = c; }
+            if (value > alpha) alpha = value;
+        } else {
+            if (s < value) { value = s; *col_out = c; }
+            if (value < beta) beta = value;
+        }
+        if (alpha >= beta) break;
+    }
+    return value;
+}
+
+/* MinimaxAgent.select_move for the side to move; returns the column (-1 without a legal move or
+ * in a finished position) and the root value. */
+int orc_minimax(u64 b1, u64 b2, int mover, int depth, int *score_out) {
+    int col;
+    const int s = mm_search(b1, b2, mover, mover, depth, -ORC_MM_INF - 2, ORC_MM_INF + 2, 1, &col);
+    if (score_out) *score_out = s;
+    return col;
+}

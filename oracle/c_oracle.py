@@ -74,6 +74,8 @@ def lib():
         L.orc_rollout.argtypes = [u64, u64, C.c_int, u64, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_philox4x32.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
         L.orc_fixed_priors.argtypes = [C.c_int, u64, u64, C.c_int, C.POINTER(C.c_float)]
+        L.orc_score_position.argtypes = [u64, u64, C.c_int]
+        L.orc_minimax.argtypes = [u64, u64, C.c_int, C.c_int, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -153,3 +155,17 @@ def az_search(b1, b2, player, sims, c_puct, evaluator, root_noise=None, eps=0.0,
     a = lib().orc_az_search(b1, b2, player, sims, c_puct, kind, fn, None, noise, eps, seed, game_id, move_index,
                             visits, C.byref(st))
     return (None if a < 0 else a), list(visits), st
+
+
+MM_INF = 1 << 30
+
+
+def score_position(b1, b2, piece):
+    return lib().orc_score_position(b1, b2, piece)
+
+
+def minimax(b1, b2, mover, depth):
+    """(column or None, root value) of the depth-limited minimax opponent for the side to move."""
+    score = C.c_int()
+    col = lib().orc_minimax(b1, b2, mover, depth, C.byref(score))
+    return (None if col < 0 else col), score.value

@@ -356,6 +356,38 @@ def capture_net():
     return meta
 
 
+# ---------------------------------------------------------------- minimax opponent
+def capture_minimax():
+    """score_position (connect_four_game.py:215-278) on random boards, and MinimaxAgent.minimax
+    (minimax/agent_code.py:34-89) on positions where colour 2 is to move - the only case in which
+    the reference agent searches for the side it moves (it always maximises for AI_PIECE = 2)."""
+    import math
+    import random
+    from nnbattle.agents.minimax import MinimaxAgent
+    random.seed(0)
+    out = {"scores": [], "searches": []}
+    for board, player in random_positions(300, seed=404, min_plies=0, max_plies=38):
+        g = ConnectFourGame()
+        g.board = board.copy()
+        out["scores"].append({"board": rp.board_to_str(board), "score1": int(g.score_position(1)),
+                              "score2": int(g.score_position(2))})
+    def enc(x):
+        return "inf" if x == math.inf else "-inf" if x == -math.inf else int(x)
+    pool = [(b, p) for b, p in random_positions(400, seed=505, min_plies=1, max_plies=36) if p == 2]
+    for depth, count in ((1, 60), (2, 60), (3, 40), (4, 40)):
+        for board, player in pool[:count]:
+            g = ConnectFourGame()
+            g.board = board.copy()
+            g.current_player = 2
+            score, col = MinimaxAgent(depth=depth).minimax(g, depth, -math.inf, math.inf, True)
+            out["searches"].append({"board": rp.board_to_str(board), "depth": depth, "score": enc(score),
+                                    "column": None if col is None else int(col),
+                                    # every move loses inside the horizon: the column is random.choice
+                                    "column_is_random": score == -math.inf})
+        print(f"[minimax] depth {depth} done", flush=True)
+    return out
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     which = sys.argv[1:] or ["rules", "search", "net"]
@@ -367,6 +399,10 @@ def main():
         with open(os.path.join(GOLDEN, "search.json"), "w") as f:
             json.dump(capture_search(), f, separators=(",", ":"))
         print("search.json written", flush=True)
+    if "minimax" in which:
+        with open(os.path.join(GOLDEN, "minimax.json"), "w") as f:
+            json.dump(capture_minimax(), f, separators=(",", ":"))
+        print("minimax.json written", flush=True)
     if "net" in which:
         with open(os.path.join(GOLDEN, "net_seed0.json"), "w") as f:
             json.dump(capture_net(), f, separators=(",", ":"))

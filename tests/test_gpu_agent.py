@@ -110,3 +110,23 @@ def test_tournament_between_two_engine_agents(torch_mod, tmp_path):
     a.evaluator, b.evaluator = "hash_q8", "hash_f32"
     res = run_tournament([a, b], num_games=4, results_dir=str(tmp_path))
     assert set(res) == {"AlphaZeroAgent_0", "AlphaZeroAgent_1", "draws"} and sum(res.values()) == 4
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_batched_minimax_vs_alphazero_tournament_equals_the_move_by_move_protocol(torch_mod, tmp_path, order):
+    """The reference's own pairing (run_tournament.py:44-48).  All games advanced together on the
+    device must end exactly as when each agent is asked for one move at a time on the host."""
+    from alphazero_amd.agent import AlphaZeroAgent
+    from alphazero_amd.game import ConnectFourGame
+    from alphazero_amd.minimax import MinimaxAgent
+    from alphazero_amd.tournament import _names, mixed_arena, play_match, run_tournament
+    az = AlphaZeroAgent(7, num_simulations=40, load_model=False)
+    az.evaluator = "hash_q8"
+    agents = [MinimaxAgent(depth=3), az] if order == 0 else [az, MinimaxAgent(depth=3)]
+    names = _names(agents)
+    game = ConnectFourGame()
+    want = [play_match(agents, names, game, i % 2) for i in range(6)]
+    got = mixed_arena(agents, 6)
+    assert ["draws" if w is None else names[w] for w in got] == want
+    tally = run_tournament(agents, num_games=6, results_dir=str(tmp_path))
+    assert tally == {n: want.count(n) for n in names} | {"draws": want.count("draws")}

@@ -297,3 +297,32 @@ def test_shard_range_partitions_games():
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_minimax_mirror_agrees_with_the_oracle_search():
+    """alphazero_amd.minimax.MinimaxAgent (host Python) against oracle/c4_oracle.c::orc_minimax, which
+    the reference's captured vectors pin (tests/golden/minimax.json)."""
+    import numpy as np
+    from alphazero_amd.game import ConnectFourGame, bits_to_board
+    from alphazero_amd.minimax import MinimaxAgent
+    from oracle import c_oracle as co
+    rng = np.random.RandomState(12)
+    checked = 0
+    while checked < 40:
+        b1 = b2 = 0
+        player = 1
+        for _ in range(int(rng.randint(0, 30))):
+            if co.lib().orc_is_terminal(b1, b2):
+                break
+            m = co.legal_mask(b1, b2)
+            _, b1, b2 = co.drop(b1, b2, player, int(rng.choice([c for c in range(7) if (m >> c) & 1])))
+            player = 3 - player
+        if co.lib().orc_is_terminal(b1, b2):
+            continue
+        g = ConnectFourGame()
+        g.board = bits_to_board(b1, b2)
+        g.current_player = player
+        for depth in (1, 2, 3):
+            want, _ = co.minimax(b1, b2, player, depth)
+            assert MinimaxAgent(depth=depth).select_move(g) == want
+        checked += 1

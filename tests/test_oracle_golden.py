@@ -208,3 +208,28 @@ def test_net_game_agreement(seed0_sd, net_golden_meta):
         agree += int(a == g["moves"][ply] and v == g["visits"][ply])
         _, player = rp.make_move(board, player, g["moves"][ply])
     assert agree == n
+
+
+def test_minimax_oracle_reproduces_reference_vectors():
+    """score_position and MinimaxAgent.minimax as captured from the reference (tests/golden/minimax.json)."""
+    import json
+    from oracle import c_oracle as co
+    from oracle import ref_port as rp
+    with open(os.path.join(GOLDEN, "minimax.json")) as f:
+        gold = json.load(f)
+    for rec in gold["scores"]:
+        b1, b2 = rp.bitboards(rp.board_from_str(rec["board"]))
+        assert co.score_position(b1, b2, 1) == rec["score1"]
+        assert co.score_position(b1, b2, 2) == rec["score2"]
+    checked = 0
+    for rec in gold["searches"]:
+        b1, b2 = rp.bitboards(rp.board_from_str(rec["board"]))
+        col, score = co.minimax(b1, b2, 2, rec["depth"])
+        want = {"inf": co.MM_INF, "-inf": -co.MM_INF}.get(rec["score"], rec["score"])
+        assert score == want
+        if not rec["column_is_random"]:
+            assert col == rec["column"]
+            checked += 1
+        else:
+            assert col == min(c for c in range(7) if (co.legal_mask(b1, b2) >> c) & 1)
+    assert checked > 150
