@@ -130,3 +130,27 @@ def test_batched_minimax_vs_alphazero_tournament_equals_the_move_by_move_protoco
     assert ["draws" if w is None else names[w] for w in got] == want
     tally = run_tournament(agents, num_games=6, results_dir=str(tmp_path))
     assert tally == {n: want.count(n) for n in names} | {"draws": want.count("draws")}
+
+
+def test_per_ply_training_samples_follow_the_cpu_game(torch_mod):
+    """self_play_samples: (planes from the mover's side, visit distribution, z) per ply, the format
+    agent_code.py:254-267 intends, against the CPU search's game."""
+    from alphazero_amd.agent import AlphaZeroAgent
+    from alphazero_amd.selfplay import self_play_samples
+    from oracle import c_oracle as co
+    from oracle import ref_port as rp
+    agent = AlphaZeroAgent(7, num_simulations=60, load_model=False)
+    agent.evaluator = "hash_q8"
+    samples = self_play_samples(agent, 2)
+    moves, visits, result, _final, _ = co.selfplay_game(60, 1.4, "hash_q8")
+    assert len(samples) == 2 * len(moves)
+    board = rp.new_board()
+    player = 1
+    for k, (mv, vis) in enumerate(zip(moves, visits)):
+        planes, probs, z = samples[k]
+        assert (planes.numpy() == rp.planes(board, player)).all()
+        want = np.array(vis, dtype=np.float64) / sum(vis)
+        assert np.allclose(probs.numpy(), want.astype(np.float32))
+        assert z == (0 if result in (0, None) else (1 if (result == 1) == (player == 1) else -1))
+        _, player = rp.make_move(board, player, mv)
+    assert all((a[0] == b[0]).all() and a[2] == b[2] for a, b in zip(samples[:len(moves)], samples[len(moves):]))
