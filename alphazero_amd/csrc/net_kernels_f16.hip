@@ -86,6 +86,9 @@ __host__ __device__ constexpr int sigma(int m) {
 
 // ABLATE (timing experiments only, 0 in the product): 1 skip staging, 2 reuse one A fragment,
 // 4 reuse one weight fragment, 8 skip the output stores.
+// NW = 32-channel tiles per wave.  2 halves the LDS reads per MFMA (a wave then owns 64 channels of
+// half the row tiles); it measured equal to 1 here - the clock rose, the cycle count with it - so
+// the product uses 1.
 //
 // FUSE_IN (first 128->128 layer only): the block's input is not read from memory but computed in
 // place - leaf encode (AlphaZeroAgent.preprocess, agent_code.py:76-89) and the 2->128 convolution
