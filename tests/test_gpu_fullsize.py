@@ -148,3 +148,24 @@ def test_config5_arena_10000_games_400_sims(gpu, oracle):
         assert all(r["plies"].tobytes() == mine[0]["plies"].tobytes() for r in mine)
         assert mine[0]["plies"]["visits"][:len(moves)].tolist() == visits
         assert (mine["result"] == co.lib().orc_result(b1, b2)).all()
+
+
+def test_config2_puct_with_network_is_reproducible_and_slot_independent(gpu, oracle):
+    """4096 slots x 200 sims/move under the PUCT rule with engine-drawn root noise and the network:
+    every block of every launch races only for batch slots, never for data, so two runs give the
+    same bytes, and 6000 games on 4096 slots contain the same first 4096 games."""
+    from alphazero_amd.engine import Engine, trajectories_to_numpy
+    co, rp = oracle
+    eng = Engine(max_games=4096, max_sims=200)
+    try:
+        eng.load_state_dict(rp.seeded_state_dict(0))
+        prm = eng.params(200, 1.4, evaluator="net", mode="az", dirichlet_alpha=0.3, dirichlet_eps=0.25, seed=17)
+        a = trajectories_to_numpy(eng.selfplay_round(4096, prm)[0]).copy()
+        b = trajectories_to_numpy(eng.selfplay_round(4096, prm)[0]).copy()
+        c = trajectories_to_numpy(eng.selfplay_round(6000, prm)[0]).copy()
+    finally:
+        eng.close()
+    assert a.tobytes() == b.tobytes()
+    assert c[:4096].tobytes() == a.tobytes()
+    games = _replay_and_check(co, c, 200, sample=range(0, 6000, 7))
+    assert len(games) > 800
