@@ -169,3 +169,24 @@ def test_config2_puct_with_network_is_reproducible_and_slot_independent(gpu, ora
     assert c[:4096].tobytes() == a.tobytes()
     games = _replay_and_check(co, c, 200, sample=range(0, 6000, 7))
     assert len(games) > 800
+
+
+def test_engine_sizes_from_one_game_to_more_than_one_kernel_group(gpu, oracle):
+    """1, 3 and 5000 slots (5000 rows span two groups of the linear layer's grid): the same
+    deterministic game comes out everywhere."""
+    from alphazero_amd.engine import Engine, trajectories_to_numpy
+    _, rp = oracle
+    sd = rp.seeded_state_dict(0)
+    seen = set()
+    for slots in (1, 3, 5000):
+        eng = Engine(max_games=slots, max_sims=64)
+        try:
+            eng.load_state_dict(sd)
+            traj, stats = eng.selfplay_round(slots, eng.params(64, 1.4, evaluator="net"))
+            rec = trajectories_to_numpy(traj)
+        finally:
+            eng.close()
+        assert all(r["plies"].tobytes() == rec[0]["plies"].tobytes() for r in rec)
+        assert stats["sims"] == slots * int(rec[0]["length"]) * 64
+        seen.add(rec[0]["plies"].tobytes())
+    assert len(seen) == 1
