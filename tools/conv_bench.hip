@@ -40,6 +40,38 @@ float run_rows(const _Float16 *in, const _Float16 *wp, const float *bias, _Float
     return ms / iters * 1000.f;
 }
 
+static const unsigned long long *g_side = nullptr;
+static const float *g_w0 = nullptr, *g_b0 = nullptr;
+
+template <int NB, int MH, int BRING, int ARING>
+float run_rows_fused(const _Float16 *, const _Float16 *wp, const float *bias, _Float16 *out, int n, int iters) {
+    constexpr size_t lds = conv_rows_lds_bytes(7, 8, NB);
+    auto k = conv_rows_f16_kernel<7, 8, NB, MH, BRING, ARING, true>;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 3; ++i) k<<<(n + NB - 1) / NB, 256 * MH, lds, 0>>>(nullptr, wp, bias, out, nullptr, n, g_side, g_w0, g_b0);
+    hipEventRecord(a, 0);
+    for (int i = 0; i < iters; ++i) k<<<(n + NB - 1) / NB, 256 * MH, lds, 0>>>(nullptr, wp, bias, out, nullptr, n, g_side, g_w0, g_b0);
+    hipEventRecord(b, 0); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    if (hipGetLastError() != hipSuccess) printf("launch error\n");
+    return ms / iters * 1000.f;
+}
+
+float run_mid_fused(const _Float16 *, const _Float16 *wp, const float *bias, _Float16 *out, int n, int iters) {
+    constexpr size_t lds = conv_lds_bytes(7, 8, 4);
+    auto k = conv_mid_f16_kernel<7, 8, 4, 2, 4, 4, true>;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 3; ++i) k<<<(n + 3) / 4, 256, lds, 0>>>(nullptr, wp, bias, out, nullptr, n, g_side, g_w0, g_b0);
+    hipEventRecord(a, 0);
+    for (int i = 0; i < iters; ++i) k<<<(n + 3) / 4, 256, lds, 0>>>(nullptr, wp, bias, out, nullptr, n, g_side, g_w0, g_b0);
+    hipEventRecord(b, 0); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    if (hipGetLastError() != hipSuccess) printf("launch error\n");
+    return ms / iters * 1000.f;
+}
+
 template <int ABL, int BR = 8, int NSET = 2>
 float run_fc(const _Float16 *a, const _Float16 *wp, float *part, int n, int iters) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -64,6 +96,21 @@ int main(int argc, char **argv) {
     hipMemcpy(wp, h.data(), 128 * 128 * 16 * 2, hipMemcpyHostToDevice);
     hipMemset(bias, 0, 512);
     const double f2 = 2.0 * 128 * 72 * 2048 * n, f4 = 2.0 * 128 * 90 * 2048 * n;
+    {   // random legal-looking side boards and 2->128 weights for the fused-input variants
+        std::vector<unsigned long long> sb(2 * (size_t)n);
+        unsigned long long x = 88172645463325252ULL;
+        for (size_t i = 0; i < sb.size(); i += 2) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            unsigned long long a = x & 0xFDFBF7EFDFBFULL; x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            sb[i] = a & x; sb[i + 1] = (x >> 3) & 0xFDFBF7EFDFBFULL & ~sb[i];
+        }
+        unsigned long long *dsb; float *w0, *b0;
+        hipMalloc(&dsb, sb.size() * 8); hipMemcpy(dsb, sb.data(), sb.size() * 8, hipMemcpyHostToDevice);
+        std::vector<float> hw(128 * 32 + 128);
+        for (size_t i = 0; i < hw.size(); ++i) hw[i] = (float)((i * 2654435761u >> 20) & 255) / 512.f - 0.2f;
+        hipMalloc(&w0, hw.size() * 4); hipMemcpy(w0, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+        g_side = dsb; g_w0 = w0; g_b0 = w0 + 128 * 32;
+    }
     struct Var { const char *name; float (*fn)(const _Float16 *, const _Float16 *, const float *, _Float16 *, int, int); double flop; float best; double mhz, cyc; };
 #define C4(NB, WPS, BR, AR, ABL, NW) {"conv4 NB=" #NB " wps=" #WPS " bring=" #BR " aring=" #AR " abl=" #ABL " NW=" #NW, run<8, 9, NB, WPS, BR, AR, ABL, NW>, f4, 1e9f}
 #define C2(NB, WPS, BR, AR, ABL, NW) {"conv2 NB=" #NB " wps=" #WPS " bring=" #BR " aring=" #AR " abl=" #ABL " NW=" #NW, run<7, 8, NB, WPS, BR, AR, ABL, NW>, f2, 1e9f}
@@ -72,7 +119,11 @@ int main(int argc, char **argv) {
 #define Q4(NB, MH, BR, AR) {"conv4 rows NB=" #NB " MH=" #MH " bring=" #BR " aring=" #AR, run_rows<8, 9, NB, MH, BR, AR>, f4, 1e9f}
 #define Q2(NB, MH, BR, AR) {"conv2 rows NB=" #NB " MH=" #MH " bring=" #BR " aring=" #AR, run_rows<7, 8, NB, MH, BR, AR>, f2, 1e9f}
         Q4(3, 1, 4, 8), Q4(3, 1, 4, 4), Q4(3, 1, 2, 8), Q4(3, 1, 8, 8), Q4(6, 2, 4, 8),
-        Q2(7, 2, 4, 8), Q2(7, 2, 4, 4), Q2(3, 1, 4, 8), Q2(3, 1, 4, 4),
+        Q2(7, 2, 4, 8), Q2(3, 1, 4, 8),
+        {"conv2 fused cell tiles NB=4 (product)", run_mid_fused, f2, 1e9f},
+        {"conv2 fused rows NB=7 MH=2 aring 8", run_rows_fused<7, 2, 4, 8>, f2, 1e9f},
+        {"conv2 fused rows NB=7 MH=2 aring 4", run_rows_fused<7, 2, 4, 4>, f2, 1e9f},
+        {"conv2 fused rows NB=3 MH=1 aring 8", run_rows_fused<3, 1, 4, 8>, f2, 1e9f},
     };
     {   // the row-tile kernels must reproduce the cell-tile kernels bit for bit
         auto check = [&](const char *name, auto ref_fn, auto new_fn, size_t halves, int nn) {
@@ -88,6 +139,8 @@ int main(int argc, char **argv) {
             check("conv4 rows NB=6 MH=2", run<8, 9, 2, 2, 4, 12, 0, 1>, run_rows<8, 9, 6, 2, 4, 8>, (size_t)nn * 90 * 128, nn);
             check("conv2 rows NB=7 MH=2", run<7, 8, 4, 2, 4, 4, 0, 1>, run_rows<7, 8, 7, 2, 4, 8>, (size_t)nn * 72 * 128, nn);
             check("conv2 rows NB=3", run<7, 8, 4, 2, 4, 4, 0, 1>, run_rows<7, 8, 3, 1, 4, 8>, (size_t)nn * 72 * 128, nn);
+            check("conv2 fused rows NB=7 MH=2", run_mid_fused, run_rows_fused<7, 2, 4, 8>, (size_t)nn * 72 * 128, nn);
+            check("conv2 fused rows NB=3", run_mid_fused, run_rows_fused<3, 1, 4, 8>, (size_t)nn * 72 * 128, nn);
         }
     }
     for (int rep = 0; rep < 5; ++rep)
