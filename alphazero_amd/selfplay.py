@@ -11,7 +11,7 @@ trajectories are all-gathered once per round (`gather_trajectories`).
 from __future__ import annotations
 
 import logging
-from typing import List, Optional, Tuple
+from typing import List, Tuple
 
 import numpy as np
 import torch
