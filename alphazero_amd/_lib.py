@@ -23,7 +23,7 @@ MODES = {"compat": MODE_COMPAT, "az": MODE_AZ}
 
 class Config(C.Structure):
     _fields_ = [("max_games", C.c_int32), ("max_sims", C.c_int32), ("device", C.c_int32),
-                ("n_weight_sets", C.c_int32), ("net_precision", C.c_int32), ("reserved", C.c_int32)]
+                ("n_weight_sets", C.c_int32), ("net_precision", C.c_int32), ("eval_cache_slots", C.c_int32)]
 
 
 class SearchParams(C.Structure):
@@ -37,7 +37,7 @@ class SearchParams(C.Structure):
 class RoundStats(C.Structure):
     _fields_ = [("games", C.c_int64), ("plies", C.c_int64), ("sims", C.c_int64),
                 ("net_leaves", C.c_int64), ("terminal_hits", C.c_int64), ("depth_sum", C.c_int64),
-                ("steps", C.c_int64), ("moves_rounds", C.c_int64)]
+                ("steps", C.c_int64), ("moves_rounds", C.c_int64), ("cache_hits", C.c_int64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

@@ -24,6 +24,14 @@ constexpr int kPathSlots = 64;      // one path entry per lane; depth <= 42
 constexpr int kMaxPlies = 42;
 
 // Pointers into the workspace (all device memory).  G = max_games.
+struct CacheEntry {             // 64 bytes
+    u64 me, opp;                // side boards as the evaluator saw them
+    float value;
+    uint32_t gen;
+    float prior[7];             // masked, renormalised priors (before any root noise)
+    uint32_t pad[3];
+};
+
 struct EngineDev {
     int32_t  max_games;
     int32_t  pool_cap;          // nodes per game = 1 + 7*max_sims
@@ -61,6 +69,12 @@ struct EngineDev {
     float   *leaf_value;        // [2G]    network / evaluator value per batch slot
     float   *leaf_logp;         // [2G][7] network log-policy per batch slot
     float   *leaf_prior;        // [2G][7] masked, renormalised priors per batch slot
+    // Evaluation cache (optional): per game a direct-mapped table of the leaves it has evaluated.
+    // An entry is valid when its generation equals cache_gen[g], which seating a new game bumps.
+    CacheEntry *cache;          // [G][cache_slots] or null
+    uint32_t *cache_gen;        // [G]
+    u64     *pend_key;          // [G][2] side boards of the game's pending leaf (to file its evaluation)
+    int32_t cache_slots;
     int32_t *counters;          // [16]   [0] = live games after the last readout
     unsigned long long *stats64; // [8]   depth, terminal hits, leaves, sims, plies (stats_reduce_kernel)
 };

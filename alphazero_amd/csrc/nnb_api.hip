@@ -112,6 +112,10 @@ size_t carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std:
     d.leaf_prior = c.take<float>(14 * G);
     d.counters = c.take<int32_t>(64);
     d.stats64 = c.take<unsigned long long>(32);
+    d.cache_gen = c.take<uint32_t>(G);
+    d.pend_key = c.take<u64>(2 * G);
+    d.cache_slots = cfg.eval_cache_slots;
+    d.cache = cfg.eval_cache_slots > 0 ? c.take<CacheEntry>(G * (size_t)cfg.eval_cache_slots) : nullptr;
     c.take<unsigned char>(kAlign);
     const size_t state_bytes = c.off;
     if (cfg.net_precision == NNB_NET_F32) {
@@ -157,6 +161,9 @@ int check_cfg(const nnb_config *cfg) {
         return fail(NNB_ERR_ARG, "n_weight_sets %d out of range [1, 8]", cfg->n_weight_sets);
     if (cfg->net_precision != NNB_NET_F16 && cfg->net_precision != NNB_NET_F32)
         return fail(NNB_ERR_ARG, "net_precision %d out of range", cfg->net_precision);
+    const int cs = cfg->eval_cache_slots;
+    if (cs != 0 && (cs < 0 || cs > 65536 || (cs & (cs - 1)) != 0))
+        return fail(NNB_ERR_ARG, "eval_cache_slots %d is neither 0 nor a power of two <= 65536", cs);
     return NNB_OK;
 }
 
@@ -210,6 +217,10 @@ int check_params(nnb_engine *e, const nnb_search_params *p, int n) {
     if (p->mode != NNB_MODE_COMPAT && p->mode != NNB_MODE_AZ) return fail(NNB_ERR_ARG, "unknown mode %d", p->mode);
     if (p->evaluator < NNB_EVAL_NET || p->evaluator > NNB_EVAL_ROLLOUT)
         return fail(NNB_ERR_ARG, "unknown evaluator %d", p->evaluator);
+    if ((p->flags & NNB_FLAG_EVAL_CACHE) && e->cfg.eval_cache_slots == 0)
+        return fail(NNB_ERR_STATE, "NNB_FLAG_EVAL_CACHE needs an engine created with eval_cache_slots > 0");
+    if ((p->flags & NNB_FLAG_EVAL_CACHE) && p->evaluator == NNB_EVAL_ROLLOUT)
+        return fail(NNB_ERR_ARG, "random rollouts are not a function of the position: no evaluation cache");
     if (p->evaluator == NNB_EVAL_ROLLOUT && (p->flags & NNB_FLAG_LOCKSTEP))
         return fail(NNB_ERR_ARG, "the rollout evaluator runs in the fused kernel only (no NNB_FLAG_LOCKSTEP)");
     if (p->mode == NNB_MODE_AZ) {
@@ -351,6 +362,7 @@ int collect_stats(nnb_engine *e, hipStream_t st, nnb_round_stats *out, long long
         out->net_leaves = (int64_t)e->host_stats[2];
         out->sims = (int64_t)e->host_stats[3];
         out->plies = (int64_t)e->host_stats[4];
+        out->cache_hits = (int64_t)e->host_stats[5];
         out->steps = steps;
         out->moves_rounds = rounds;
     }

@@ -423,7 +423,11 @@ __device__ void readout_game(const EngineDev &e, const SearchDev &p, int g, int3
 // simulation budget is used up ends its move here - readout, move, trajectory, retirement or the
 // next game of the round, fresh root - before the step carries on with its next search.  With
 // root noise to draw, turnover_kernel does the same ahead of the step instead.
-template <bool AZ, bool HEADS, bool TURNOVER>
+//
+// CACHE (NNB_FLAG_EVAL_CACHE): the evaluation of every leaf is filed in the game's direct-mapped
+// table when it arrives; a leaf whose position is already there ends its simulation on the spot
+// with the filed value and priors, exactly as the fresh evaluation would have a round later.
+template <bool AZ, bool HEADS, bool TURNOVER, bool CACHE>
 __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e, SearchDev p, int parity, HeadsPair hp,
                                                                     RoundDev round) {
     __shared__ int s_want[kStepGames];       // 0 = no leaf, 1 + batch otherwise
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
     u64 leaf_me = 0, leaf_opp = 0;
     unsigned leaf_legal_mask = 0;
     int leaf_len = 0, leaf_path = 0;
-    int sims_done = 0, n_nodes = 0, depth_sum = 0, term_hits = 0;
+    int sims_done = 0, n_nodes = 0, depth_sum = 0, term_hits = 0, cache_hits = 0;
     if (live) {
     Node *pool = e.nodes + (size_t)g * e.pool_cap;
     float *prior = e.prior + (size_t)g * e.pool_cap;
@@ -469,6 +473,9 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
     const int player = e.root_player[g];
     const u64 r1 = e.root_boards[2 * g], r2 = e.root_boards[2 * g + 1];
     batch = two_batches ? player - 1 : 0;      // every leaf of a search is judged by the root mover's network
+    CacheEntry *table = nullptr;
+    uint32_t gen = 0;
+    if constexpr (CACHE) { table = e.cache + (size_t)g * e.cache_slots; gen = e.cache_gen[g]; }
 
     // masks of the leaves batched by the previous step (this step writes the other half)
     const uint8_t *legal_in = e.leaf_legal + (size_t)(parity ^ 1) * 2 * e.max_games;
@@ -499,6 +506,12 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
         } else {
             v = (double)e.leaf_value[pend];              // value.item(), agent_code.py:213
             if (AZ) pr = lane < 7 ? e.leaf_prior[pend * 7 + lane] : 0.0f;
+        }
+        if constexpr (CACHE) {                            // file the evaluation under the leaf's position
+            const u64 kme = e.pend_key[2 * g], kopp = e.pend_key[2 * g + 1];
+            CacheEntry *ce = table + (c4::mix64(kme, kopp) & (u64)(e.cache_slots - 1));
+            if (lane == 0) { ce->me = kme; ce->opp = kopp; ce->value = (float)v; ce->gen = gen; }
+            if (AZ && lane < 7) ce->prior[lane] = pr;
         }
         if (AZ) {
             const int leaf = __shfl(mypath, len - 1);
@@ -543,12 +556,33 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
             ++sims_done; ++term_hits; ++spot;
             continue;
         }
-        if (!AZ) n_nodes += expand_compat(pool, node, n_nodes, legal, lane);
         // COMPAT: the leaf is encoded from the root mover's side at every depth
         // (agent_code.py:85); AZ: from the side to move at the leaf
-        want = true;
         leaf_me = mover == 1 ? c1 : c2;
         leaf_opp = mover == 1 ? c2 : c1;
+        if constexpr (CACHE) {
+            const u64 kopp = leaf_opp | ((u64)batch << 63);      // the two networks of an arena do not share entries
+            const CacheEntry *ce = table + (c4::mix64(leaf_me, kopp) & (u64)(e.cache_slots - 1));
+            if (ce->gen == gen && ce->me == leaf_me && ce->opp == kopp) {
+                const double v = (double)ce->value;
+                if (AZ) {
+                    float pr = lane < 7 ? ce->prior[lane] : 0.0f;
+                    if (len == 1 && p.dirichlet_eps > 0.0 && lane < 7)
+                        pr = (float)((1.0 - p.dirichlet_eps) * (double)pr + p.dirichlet_eps * (double)e.root_noise[7 * g + lane]);
+                    n_nodes += expand_az(pool, prior, node, n_nodes, legal, pr, lane);
+                    backup_az(pool, mypath, len, v, lane);
+                } else {
+                    n_nodes += expand_compat(pool, node, n_nodes, legal, lane);
+                    backup_path(pool, mypath, len, v, lane);
+                }
+                wave_mem_sync();
+                ++sims_done; ++cache_hits; ++spot;
+                continue;
+            }
+            if (lane == 0) { e.pend_key[2 * g] = leaf_me; e.pend_key[2 * g + 1] = kopp; }
+        }
+        if (!AZ) n_nodes += expand_compat(pool, node, n_nodes, legal, lane);
+        want = true;
         leaf_legal_mask = legal;
         leaf_len = len;
         leaf_path = mypath;
@@ -583,7 +617,7 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
         e.n_nodes[g] = n_nodes;
         e.pending[g] = pend_out;
         int32_t *st = e.game_stats + 8 * g;
-        st[0] += depth_sum; st[1] += term_hits; st[2] += want ? 1 : 0;
+        st[0] += depth_sum; st[1] += term_hits; st[2] += want ? 1 : 0; st[5] += cache_hits;
     }
 }
 
@@ -700,6 +734,7 @@ __device__ bool seat_game(const EngineDev &e, const RoundDev &r, int g, int j) {
     e.ply[g] = 0;
     e.game_id[g] = r.first_game_id + j;
     e.traj_index[g] = j;
+    e.cache_gen[g] += 1;                                      // the new game starts with an empty evaluation cache
     return true;
 }
 
@@ -810,6 +845,7 @@ __global__ void search_init_kernel(EngineDev e, const u64 *__restrict__ boards,
     const u64 b1 = boards[2 * g] & c4::kBoardMask, b2 = boards[2 * g + 1] & c4::kBoardMask & ~b1;
     e.root_boards[2 * g] = b1; e.root_boards[2 * g + 1] = b2;
     e.root_player[g] = players[g] == 2 ? 2 : 1;
+    e.cache_gen[g] += 1;
     e.active[g] = 1;
     e.ply[g] = 0;
     e.game_id[g] = game_base + g;
@@ -822,12 +858,13 @@ __global__ void search_init_kernel(EngineDev e, const u64 *__restrict__ boards,
 // and counters[12] (plies).
 __global__ void stats_reduce_kernel(EngineDev e) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
-    long long v[5] = {0, 0, 0, 0, 0};
+    long long v[6] = {0, 0, 0, 0, 0, 0};
     if (g < e.n_games) {
         for (int k = 0; k < 4; ++k) v[k] = e.game_stats[8 * g + k];
         v[4] = e.game_stats[8 * g + 4] + e.ply[g];
+        v[5] = e.game_stats[8 * g + 5];
     }
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < 6; ++k) {
         long long x = v[k];
         for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
         if ((threadIdx.x & 63) == 0 && x)
@@ -1013,8 +1050,14 @@ static void launch_tree_step_t(hipStream_t st, const EngineDev &e, const SearchD
                                const RoundDev *turnover, size_t lds) {
     const int blocks = cdiv(e.n_games, kStepGames), threads = kStepGames * 64;
     const RoundDev none = {nullptr, nullptr, nullptr, 0, 0};
-    if (turnover) tree_step_kernel<AZ, HEADS, true><<<blocks, threads, lds, st>>>(e, p, parity, heads, *turnover);
-    else tree_step_kernel<AZ, HEADS, false><<<blocks, threads, lds, st>>>(e, p, parity, heads, none);
+    const bool cache = (p.flags & NNB_FLAG_EVAL_CACHE) && e.cache;
+    if (turnover) {
+        if (cache) tree_step_kernel<AZ, HEADS, true, true><<<blocks, threads, lds, st>>>(e, p, parity, heads, *turnover);
+        else tree_step_kernel<AZ, HEADS, true, false><<<blocks, threads, lds, st>>>(e, p, parity, heads, *turnover);
+    } else {
+        if (cache) tree_step_kernel<AZ, HEADS, false, true><<<blocks, threads, lds, st>>>(e, p, parity, heads, none);
+        else tree_step_kernel<AZ, HEADS, false, false><<<blocks, threads, lds, st>>>(e, p, parity, heads, none);
+    }
 }
 
 // turnover != null: games whose budget is used up end their move inside the step (see TURNOVER)
@@ -1041,11 +1084,15 @@ hipError_t prepare_tree_fused(size_t lds_bytes) {
 
 // The PUCT step kernel of a two-network arena stages 2 x 8 head rows = 64 KB of dynamic LDS.
 hipError_t prepare_tree_step() {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(tree_step_kernel<true, true, false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4096);
-    if (err != hipSuccess) return err;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(tree_step_kernel<true, true, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4096);
+    const void *k[4] = {reinterpret_cast<const void *>(tree_step_kernel<true, true, false, false>),
+                        reinterpret_cast<const void *>(tree_step_kernel<true, true, true, false>),
+                        reinterpret_cast<const void *>(tree_step_kernel<true, true, false, true>),
+                        reinterpret_cast<const void *>(tree_step_kernel<true, true, true, true>)};
+    for (const void *f : k) {
+        hipError_t err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4096);
+        if (err != hipSuccess) return err;
+    }
+    return hipSuccess;
 }
 
 void launch_tree_fused(hipStream_t st, const EngineDev &e, const SearchDev &p, size_t lds_bytes) {

@@ -46,7 +46,7 @@ class Engine:
     """One engine = one GPU, one workspace, up to `max_games` concurrent games."""
 
     def __init__(self, max_games: int, max_sims: int, device: Optional[torch.device] = None,
-                 n_weight_sets: int = 1, precision: str = "f16"):
+                 n_weight_sets: int = 1, precision: str = "f16", eval_cache_slots: int = 0):
         if not torch.cuda.is_available():
             raise NnbError("no GPU visible: the engine runs on an MI355X only (there is no CPU path)")
         self.lib = _lib.load()
@@ -56,7 +56,7 @@ class Engine:
         self.max_games, self.max_sims = int(max_games), int(max_sims)
         self.precision = precision
         self.cfg = Config(self.max_games, self.max_sims, self.device.index, int(n_weight_sets),
-                          PRECISIONS[precision], 0)
+                          PRECISIONS[precision], int(eval_cache_slots))
         nbytes = C.c_size_t()
         check(self.lib.nnb_workspace_bytes(C.byref(self.cfg), C.byref(nbytes)), "nnb_workspace_bytes")
         self.workspace_bytes = nbytes.value
@@ -96,10 +96,11 @@ class Engine:
                dirichlet_alpha: float = 0.0, dirichlet_eps: float = 0.0, seed: int = 0,
                lockstep: bool = False, rng_move_index: int = 0, rng_game_base: int = 0,
                weight_set_colour2: Optional[int] = None, separate_heads: bool = False,
-               sync_moves: bool = False) -> SearchParams:
+               sync_moves: bool = False, eval_cache: bool = False) -> SearchParams:
         ev = EVALUATORS[evaluator] if isinstance(evaluator, str) else int(evaluator)
         md = MODES[mode] if isinstance(mode, str) else int(mode)
-        return SearchParams(md, ev, int(sims), int(weight_set), int(bool(lockstep)) | (2 if separate_heads else 0) | (4 if sync_moves else 0),
+        return SearchParams(md, ev, int(sims), int(weight_set), int(bool(lockstep)) | (2 if separate_heads else 0) | (4 if sync_moves else 0)
+                            | (8 if eval_cache else 0),
                             int(rng_move_index),
                             int(rng_game_base), 0 if weight_set_colour2 is None else int(weight_set_colour2) + 1,
                             float(c_puct), float(dirichlet_alpha), float(dirichlet_eps),

@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--opening-plies", type=int, default=0,
                     help="random legal moves played before self-play starts (0 = every game from the empty board, as the\n"
                          "reference plays; its search is deterministic, so those games are all the same game)")
+    ap.add_argument("--no-eval-cache-line", action="store_true",
+                    help="skip the extra, untimed round with the per-game evaluation cache (reported apart from `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -117,7 +119,9 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     G = args.games
-    engine = Engine(max_games=G, max_sims=args.sims, device=device, precision=args.precision)
+    cache_line = not args.no_eval_cache_line
+    engine = Engine(max_games=G, max_sims=args.sims, device=device, precision=args.precision,
+                    eval_cache_slots=2048 if cache_line else 0)
     engine.load_state_dict(seeded_state_dict(0))
     params = engine.params(args.sims, C_PUCT, evaluator="net", mode="compat")
     traj = torch.empty((G, TRAJECTORY_BYTES), dtype=torch.uint8, device=device)
@@ -155,6 +159,22 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = engine.profile_report()
     engine.profile(False)
+
+    # One more round, outside the timed region and apart from `value`: the same games with the per-game
+    # evaluation cache (a leaf whose position the game has already evaluated is not sent to the
+    # network again).  The reference evaluates every leaf, so the headline number does too.
+    cached = None
+    if cache_line:
+        cparams = engine.params(args.sims, C_PUCT, evaluator="net", mode="compat", eval_cache=True)
+        fence()
+        c0 = time.perf_counter()
+        _, cst = engine.selfplay_round(G, cparams, first_game_id=0, out=traj, start_boards=start_boards,
+                                       start_players=start_players)
+        torch.cuda.synchronize(device)
+        cdt = time.perf_counter() - c0
+        cached = {"games_per_s_this_rank": cst["games"] / cdt, "sims_per_s_this_rank": cst["sims"] / cdt,
+                  "net_leaves": cst["net_leaves"], "cache_hits": cst["cache_hits"],
+                  "note": "same trajectories; not part of `value`"}
 
     # all-gather cost alone (reported, also part of the timed region above)
     gather_ms = None
@@ -240,6 +260,8 @@ def main():
                               "unit": "GB/s", "frac": tree_gbs / PEAK_HBM_GBS, "traffic": None,
                               "bytes_per_sim": tree_bytes_per_sim, "avg_launch_ms": tree_ms},
         }
+        if cached is not None:
+            out["with_eval_cache"] = cached
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.sims, plies_per_game)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

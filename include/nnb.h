@@ -79,7 +79,15 @@ enum nnb_flags {
      * (S+1 tree steps, then one readout for everybody) instead of letting every game end its
      * move and start the next one as soon as its own simulations are done.  Same games; the
      * default keeps the leaf batch fuller when games differ. */
-    NNB_FLAG_SYNC_MOVES = 4
+    NNB_FLAG_SYNC_MOVES = 4,
+    /* Lock-step path: remember every leaf evaluation of a game (value, masked priors) in a per-game
+     * hash table and reuse it when the same position comes up again in that game - transpositions
+     * inside a search, and under PUCT the positions earlier moves already looked at.  A hit ends
+     * its simulation on the spot like a finished position does.  The evaluators are functions of
+     * the position, so the games are the same byte for byte; only the number of leaves sent to
+     * the network drops.  Off by default (the reference evaluates every leaf, agent_code.py:195);
+     * needs an engine created with eval_cache_slots > 0. */
+    NNB_FLAG_EVAL_CACHE = 8
 };
 
 /* How the network's three big layers multiply.  Both accumulate in float32 and keep bias,
@@ -95,7 +103,8 @@ typedef struct nnb_config {
     int32_t device;      /* HIP device ordinal the workspace lives on              */
     int32_t n_weight_sets; /* resident network weight sets (1, or 2 for an arena)  */
     int32_t net_precision; /* nnb_precision: arithmetic of the conv / linear layers */
-    int32_t reserved;
+    int32_t eval_cache_slots; /* 0, or a power of two <= 65536: per-game table of leaf evaluations
+                                 (64 B per slot) for NNB_FLAG_EVAL_CACHE                       */
 } nnb_config;
 
 typedef struct nnb_search_params {
@@ -142,6 +151,7 @@ typedef struct nnb_round_stats {
     int64_t depth_sum;           /* sum of selection depths over all simulations    */
     int64_t steps;               /* lock-step iterations (tree kernel + forward)    */
     int64_t moves_rounds;        /* move rounds (<= 42)                             */
+    int64_t cache_hits;          /* simulations answered by the evaluation cache    */
 } nnb_round_stats;
 
 /* ---- library ----------------------------------------------------------- */

@@ -3,6 +3,7 @@
   tree     pure-tree search, PUCT with uniform priors + bitboard random rollouts, 800 sims/move
            (whole move in one launch, node pool in LDS); also the reference rule with the same evaluator
   az       PUCT + Dirichlet root noise with the network, 4096 games x 200 sims/move
+  cache    the headline workload and PUCT self-play with the per-game evaluation cache on and off
   diverse  the reference rule with the network, 4 random opening plies, 4 x as many games as slots
   arena    two networks against each other, 400 sims/move, starter alternates, both nets batched
 
@@ -76,6 +77,16 @@ def main():
                               "net_leaves": st["net_leaves"], "terminal_hits": st["terminal_hits"]}))
             report(f"az: {total} games on {G} slots x 200 sims/move, PUCT + Dirichlet(0.3, eps 0.25), network", dt, st,
                    {"leaf_batch_fill": st["net_leaves"] / max(st["steps"] * G, 1)})
+        eng.close()
+    if "cache" in a.what:
+        eng = Engine(max_games=G, max_sims=200, eval_cache_slots=2048)
+        eng.load_state_dict(seeded_state_dict(0))
+        for mode, extra, total in (("compat", {}, G), ("az", dict(dirichlet_alpha=0.3, dirichlet_eps=0.25, seed=11), 4 * G)):
+            for cache in (False, True):
+                p = eng.params(200, 1.4, evaluator="net", mode=mode, eval_cache=cache, **extra)
+                dt, st, _ = timed_round(eng, G, p, total=total)
+                report(f"{mode}, network, {total} games on {G} slots x 200 sims/move, evaluation cache {'on' if cache else 'off'}",
+                       dt, st, {"net_leaves": st["net_leaves"], "cache_hits": st["cache_hits"], "steps": st["steps"]})
         eng.close()
     if "diverse" in a.what:
         from alphazero_amd.selfplay import random_openings
