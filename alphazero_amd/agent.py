@@ -65,6 +65,7 @@ class AlphaZeroAgent(Agent):
         self.model = Connect4Net(state_dim, action_dim).to(self.device)
         self.logger = self.__class__.logger
         self.evaluator = "net"          # fixed evaluators ("const", "hash_q8", "hash_f32") for parity runs
+        self.eval_cache = False         # True: a game does not send one position to the network twice (same moves)
         self._engine = None
         self._engine_key = None
         self._weights_stamp = None
@@ -80,11 +81,12 @@ class AlphaZeroAgent(Agent):
         """The device engine sized for this agent (created on first use, re-created if the
         simulation count or the requested game count grows)."""
         from .engine import Engine
-        key = (max(int(max_games), 1), max(int(self.num_simulations), int(max_sims), 1))
-        if self._engine is None or self._engine_key[0] < key[0] or self._engine_key[1] < key[1]:
+        key = (max(int(max_games), 1), max(int(self.num_simulations), int(max_sims), 1), bool(self.eval_cache))
+        if (self._engine is None or self._engine_key[0] < key[0] or self._engine_key[1] < key[1]
+                or self._engine_key[2] != key[2]):
             if self._engine is not None:
                 self._engine.close()
-            self._engine = Engine(max_games=key[0], max_sims=key[1])
+            self._engine = Engine(max_games=key[0], max_sims=key[1], eval_cache_slots=2048 if key[2] else 0)
             self._engine_key = key
             self._weights_stamp = None
         if self.evaluator == "net":
@@ -150,7 +152,8 @@ class AlphaZeroAgent(Agent):
         """
         eng = self.engine(1, num_simulations)
         b1, b2 = board_to_bits(np.asarray(env.board))
-        params = eng.params(num_simulations, self.c_puct, evaluator=self.evaluator, mode="compat")
+        params = eng.params(num_simulations, self.c_puct, evaluator=self.evaluator, mode="compat",
+                            eval_cache=self.eval_cache)
         visits, action, _rootv, _stats = eng.search(np.array([[b1, b2]], dtype=np.uint64),
                                                     np.array([env.current_player], dtype=np.int8), params)
         if int(action[0]) < 0:

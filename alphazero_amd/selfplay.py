@@ -73,7 +73,8 @@ def play_games(agent, num_games: int, first_game_id: int = 0, start_boards=None,
     if num_games <= 0:
         return np.zeros(0, dtype=_trajectory_dtype()), {}
     eng = agent.engine(min(num_games, MAX_CONCURRENT_GAMES))
-    params = eng.params(agent.num_simulations, agent.c_puct, evaluator=agent.evaluator, mode="compat")
+    params = eng.params(agent.num_simulations, agent.c_puct, evaluator=agent.evaluator, mode="compat",
+                        eval_cache=getattr(agent, "eval_cache", False))
     traj, stats = eng.selfplay_round(num_games, params, first_game_id=first_game_id, start_boards=start_boards,
                                      start_players=start_players)
     return trajectories_to_numpy(traj), dict(stats)

@@ -76,3 +76,23 @@ def test_cache_flag_needs_a_cache(rp):
         eng.close()
     with pytest.raises(NnbError):
         Engine(max_games=4, max_sims=16, eval_cache_slots=1000)
+
+
+def test_agent_level_switch(rp):
+    """agent.eval_cache = True: same self-play samples, fewer network rows."""
+    from alphazero_amd.agent import AlphaZeroAgent
+    from alphazero_amd.selfplay import play_games
+    import torch
+    torch.manual_seed(0)
+    agent = AlphaZeroAgent(7, num_simulations=60, load_model=False)
+    plain, st0 = play_games(agent, 3)
+    agent.eval_cache = True
+    cached, st1 = play_games(agent, 3)
+    assert plain.tobytes() == cached.tobytes()
+    assert st1["cache_hits"] > 0 and st1["net_leaves"] < st0["net_leaves"]
+    from alphazero_amd.game import ConnectFourGame
+    agent.eval_cache = False
+    a = agent.select_move(ConnectFourGame())
+    agent.eval_cache = True
+    b = agent.select_move(ConnectFourGame())
+    assert a[0] == b[0] and torch.equal(a[1], b[1])
