@@ -408,7 +408,7 @@ constexpr int kStepGames = 16;                    // games (wavefronts) per bloc
 // but at most this many per step: a game deep in a won position would otherwise run its whole
 // budget inside one launch while the other 15 waves of its block (and the batch) wait.  The
 // order of a game's simulations is unchanged, so results are too; S+1 steps still suffice.
-constexpr int kTerminalSimsPerStep = 3;
+constexpr int kTerminalSimsPerStep = 6;
 
 __device__ void readout_game(const EngineDev &e, const SearchDev &p, int g, int32_t *__restrict__ visits_out,
                              int8_t *__restrict__ action_out, double *__restrict__ root_value_out,
