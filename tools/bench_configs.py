@@ -84,7 +84,10 @@ def main():
         for mode, extra, total in (("compat", {}, G), ("az", dict(dirichlet_alpha=0.3, dirichlet_eps=0.25, seed=11), 4 * G)):
             for cache in (False, True):
                 p = eng.params(200, 1.4, evaluator="net", mode=mode, eval_cache=cache, **extra)
+                eng.profile(True)
                 dt, st, _ = timed_round(eng, G, p, total=total)
+                print(json.dumps({"kernel_ms": {k: round(v["avg_ms"], 4) for k, v in eng.profile_report().items()}}))
+                eng.profile(False)
                 report(f"{mode}, network, {total} games on {G} slots x 200 sims/move, evaluation cache {'on' if cache else 'off'}",
                        dt, st, {"net_leaves": st["net_leaves"], "cache_hits": st["cache_hits"], "steps": st["steps"]})
         eng.close()
