@@ -79,7 +79,7 @@ def main():
                    {"leaf_batch_fill": st["net_leaves"] / max(st["steps"] * G, 1)})
         eng.close()
     if "cache" in a.what:
-        eng = Engine(max_games=G, max_sims=200, eval_cache_slots=2048)
+        eng = Engine(max_games=G, max_sims=200, eval_cache_slots=int(os.environ.get("NNB_CACHE_SLOTS", "2048")))
         eng.load_state_dict(seeded_state_dict(0))
         for mode, extra, total in (("compat", {}, G), ("az", dict(dirichlet_alpha=0.3, dirichlet_eps=0.25, seed=11), 4 * G)):
             for cache in (False, True):
