@@ -80,6 +80,31 @@ def play_games(agent, num_games: int, first_game_id: int = 0, start_boards=None,
     return trajectories_to_numpy(traj), dict(stats)
 
 
+def distributed_play_games(agent, num_games: int, first_game_id: int = 0, group=None, device=None):
+    """One process per GPU: this rank plays its contiguous share of `num_games` (shard_range) and
+    one all-gather puts every trajectory record on every rank, in game order - the replay-buffer
+    exchange, the only communication of a self-play round.  Shares may differ by one game; the
+    shorter ones are padded for the collective and trimmed afterwards.  Without a process group this
+    is play_games.  Returns (records of all games, this rank's statistics)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return play_games(agent, num_games, first_game_id=first_game_id)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    first, last = shard_range(int(num_games), rank, world)
+    records, stats = play_games(agent, last - first, first_game_id=first_game_id + first)
+    per_rank = -(-int(num_games) // world)
+    padded = np.zeros(per_rank, dtype=_trajectory_dtype())
+    padded[:last - first] = records
+    local = torch.from_numpy(padded.view(np.uint8).reshape(per_rank, -1))
+    if device is not None:
+        local = local.to(device)
+    everything = gather_trajectories(local, group).cpu().numpy().reshape(-1).view(_trajectory_dtype())
+    out = np.concatenate([everything[r * per_rank:r * per_rank + (shard_range(int(num_games), r, world)[1]
+                                                                  - shard_range(int(num_games), r, world)[0])]
+                          for r in range(world)])
+    return out, stats
+
+
 def _trajectory_dtype():
     from .engine import TRAJECTORY_DTYPE
     return TRAJECTORY_DTYPE

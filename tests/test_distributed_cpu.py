@@ -60,6 +60,30 @@ def test_two_rank_trajectory_allgather(tmp_path):
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
 
 
+def _worker_uneven(rank, world, port, n_games, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from alphazero_amd import selfplay
+        selfplay.play_games = lambda agent, n, first_game_id=0, **kw: (_fake_records(first_game_id, first_game_id + n),
+                                                                       {"games": n})
+        rec, stats = selfplay.distributed_play_games(object(), n_games, first_game_id=100)
+        want = _fake_records(100, 100 + n_games)
+        assert rec.shape == want.shape and rec.tobytes() == want.tobytes()
+        first, last = shard_range(n_games, rank, world)
+        assert stats == {"games": last - first}
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_play_games_with_uneven_shares(tmp_path):
+    world, n_games = 2, 7                      # shares of 4 and 3 games
+    mp.spawn(_worker_uneven, args=(world, _free_port(), n_games, str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
 def test_gather_is_identity_without_a_process_group():
     local = torch.zeros((3, TRAJECTORY_DTYPE.itemsize), dtype=torch.uint8)
     assert gather_trajectories(local) is local
