@@ -57,6 +57,7 @@ struct NetBuffers {            // activations, channels-last float32
     float *fc;                 // [G][1024]
     float *fcpart;             // [2][G][1024] split-K partial sums (f16 path)
     float *fc_b1, *fcpart_b1;  // the same two for the second leaf batch of a two-network arena
+    float *act1_b1, *act2_b1, *act3_b1;   // and its convolution buffers (the two batches run on two streams)
     int max_rows;              // G
 };
 enum NetStage { NET_CONV0 = 0, NET_CONV2 = 1, NET_CONV4 = 2, NET_FC = 3, NET_HEADS = 4 };

@@ -73,6 +73,8 @@ struct nnb_engine {
     int32_t *host_counters = nullptr;      // pinned, 16 ints
     unsigned long long *host_stats = nullptr;   // pinned, 8 u64
     size_t fused_lds_prepared = 0;
+    hipStream_t side_stream = nullptr;     // second forward pass of a two-network arena
+    hipEvent_t fork_event = nullptr, join_event = nullptr;
     bool prof_on = false;
     bool prof_events = false;
     int prof_stride = 1;
@@ -125,6 +127,10 @@ size_t carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std:
         b.fc = c.take<float>(G * 1024);
         b.fc_b1 = c.take<float>(G * 1024);
         b.fcpart = b.fcpart_b1 = nullptr;
+        const bool two = cfg.n_weight_sets > 1;          // second batch only exists with two networks
+        b.act1_b1 = two ? c.take<float>(G * 56 * 128) : nullptr;
+        b.act2_b1 = two ? c.take<float>(G * 72 * 128) : nullptr;
+        b.act3_b1 = two ? c.take<float>(G * 90 * 128) : nullptr;
     } else {                                // half activations; the 2->128 layer's output stays in LDS
         b.act1 = nullptr;
         b.act2 = reinterpret_cast<float *>(c.take<uint16_t>(G * 72 * 128));
@@ -132,6 +138,10 @@ size_t carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std:
         b.fc = b.fc_b1 = nullptr;
         b.fcpart = c.take<float>(2 * G * 1024);
         b.fcpart_b1 = c.take<float>(2 * G * 1024);
+        const bool two = cfg.n_weight_sets > 1;
+        b.act1_b1 = nullptr;
+        b.act2_b1 = two ? reinterpret_cast<float *>(c.take<uint16_t>(G * 72 * 128)) : nullptr;
+        b.act3_b1 = two ? reinterpret_cast<float *>(c.take<uint16_t>(G * 90 * 128)) : nullptr;
     }
     b.max_rows = cfg.max_games;
     w.resize(cfg.n_weight_sets);
@@ -249,11 +259,14 @@ void net_stage(nnb_engine *e, hipStream_t st, int stage, const NetWeights &w, co
         launch_net_stage_f16(st, stage, w, b, side, legal, logp, value, prior, count_ptr, n_max);
 }
 
-// Activation buffers of leaf batch `batch`: the convolutions' buffers are shared (the batches run
-// one after the other), the linear layer's output is per batch because the tree step reads it later.
+// Activation buffers of leaf batch `batch`: the second batch of a two-network arena has buffers of
+// its own, so the two forward passes can run side by side on two streams.
 NetBuffers batch_buffers(const nnb_engine *e, int batch) {
     NetBuffers b = e->buf;
-    if (batch == 1) { b.fc = b.fc_b1; b.fcpart = b.fcpart_b1; }
+    if (batch == 1) {
+        b.fc = b.fc_b1; b.fcpart = b.fcpart_b1;
+        b.act1 = b.act1_b1; b.act2 = b.act2_b1; b.act3 = b.act3_b1;
+    }
     return b;
 }
 
@@ -305,6 +318,17 @@ void lockstep_step(nnb_engine *e, hipStream_t st, const nnb_search_params &p, co
     const EngineDev &d = e->dev;
     { ProfScope ps(e, 0, st); launch_tree_step(st, d, sd, parity, plan.heads, turnover); }
     if (!evaluate) return;
+    if (plan.nbatch == 2 && p.evaluator == NNB_EVAL_NET && e->side_stream) {
+        // two networks: the second batch's forward pass runs on the engine's side stream, next to the
+        // first one's, and joins before the next tree step
+        (void)hipEventRecord(e->fork_event, st);
+        (void)hipStreamWaitEvent(e->side_stream, e->fork_event, 0);
+        forward_leaves(e, e->side_stream, sd.wset[1], 1, parity, d.n_games, !plan.heads.fused);
+        (void)hipEventRecord(e->join_event, e->side_stream);
+        forward_leaves(e, st, sd.wset[0], 0, parity, d.n_games, !plan.heads.fused);
+        (void)hipStreamWaitEvent(st, e->join_event, 0);
+        return;
+    }
     for (int b = 0; b < plan.nbatch; ++b) {
         if (p.evaluator == NNB_EVAL_NET) forward_leaves(e, st, sd.wset[b], b, parity, d.n_games, !plan.heads.fused);
         else launch_fixed_eval(st, d, sd, b, parity);
@@ -417,6 +441,11 @@ int nnb_engine_create(const nnb_config *cfg, void *workspace, size_t workspace_b
     HIP_TRY(hipMemcpyAsync(e->dev.log_table, logt.data(), logt.size() * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->host_counters), 64 * sizeof(int32_t), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->host_stats), 32 * sizeof(unsigned long long), hipHostMallocDefault));
+    if (cfg->n_weight_sets > 1) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e->fork_event, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->join_event, hipEventDisableTiming));
+    }
     HIP_TRY(prepare_net_kernels());
     HIP_TRY(prepare_tree_step());
     HIP_TRY(prepare_net_kernels_f16());
@@ -431,6 +460,9 @@ int nnb_engine_destroy(nnb_engine *e) {
     if (e->prof_events)
         for (auto &p : e->prof)
             for (int i = 0; i < kProfSamples; ++i) { (void)hipEventDestroy(p.start[i]); (void)hipEventDestroy(p.stop[i]); }
+    if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
+    if (e->fork_event) (void)hipEventDestroy(e->fork_event);
+    if (e->join_event) (void)hipEventDestroy(e->join_event);
     if (e->host_counters) (void)hipHostFree(e->host_counters);
     if (e->host_stats) (void)hipHostFree(e->host_stats);
     delete e;
