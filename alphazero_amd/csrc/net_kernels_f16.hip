@@ -530,18 +530,29 @@ constexpr int FCH_K = 11520, FCH_N = 1024, FCH_BM = 128, FCH_BN = 256, FCH_BK = 
 
 // MTR = 32-row tiles per block (1..4): the kernel picks the smallest that covers the batch with the
 // launched blocks, so a partly filled batch costs proportionally less instead of leaving CUs idle.
-template <int MTR, int ABLATE, int BR, int NSET>
+// WAVES = waves per block: 4 (a block owns 256 columns) or 1 (64 columns per block, MTR = 1 only: the
+// small-batch form, 16 column blocks x 2 K halves per row block so that a handful of rows still spreads
+// the 23.6 MB of weights over many CUs).  A wave's arithmetic is the same either way.
+template <int MTR, int ABLATE, int BR, int NSET, int WAVES = 4>
 __device__ __forceinline__ void fc_f16_tile(const _Float16 *__restrict__ a, const _Float16 *__restrict__ wp,
                                             float *__restrict__ part, int count, int max_rows,
                                             uint4 (&lds)[3][FCH_BM * 8]) {
+    static_assert(WAVES == 4 || (WAVES == 1 && MTR == 1), "one-wave blocks are the small-batch form");
     const int bid = blockIdx.x;
-    const int x = bid & 7, i = bid >> 3;                    // i in [0, 32 * groups)
-    const int grp = i >> 5, ii = i & 31;
-    const int mb = (grp * 8 + x) * 4 + (ii & 3);
-    const int nb = (ii >> 2) & 3, ksp = ii >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, h = lane >> 5;
+    int mb, nb, ksp, w;
+    if constexpr (WAVES == 4) {
+        const int x = bid & 7, i = bid >> 3;                // i in [0, 32 * groups)
+        const int grp = i >> 5, ii = i & 31;
+        mb = (grp * 8 + x) * 4 + (ii & 3);
+        nb = (ii >> 2) & 3; ksp = ii >> 4;
+        w = tid >> 6;
+    } else {
+        const int q = bid & 31;
+        mb = bid >> 5; nb = q & 3; w = (q >> 2) & 3; ksp = q >> 4;
+    }
     const int row0 = mb * (32 * MTR);
     if (row0 >= count) return;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, m = lane & 31, h = lane >> 5;
 #ifdef NNB_CONV_BENCH_CLOCKS
     const unsigned long long dbg_c0 = __builtin_readcyclecounter(), dbg_w0 = wall_clock64();
 #endif
@@ -558,15 +569,16 @@ __device__ __forceinline__ void fc_f16_tile(const _Float16 *__restrict__ a, cons
     int sdst##C;                                                                                  \
     const uint4 *abase##C;                                                                        \
     {                                                                                             \
-        int e = tid + 256 * (C), srow = e >> 3, scol = e & 7;                                     \
+        int e = tid + 64 * WAVES * (C), srow = e >> 3, scol = e & 7;                              \
         sdst##C = srow * 8 + (scol ^ ((srow >> 1) & 7));                                          \
         int r = min(row0 + srow, max_rows - 1);                                                   \
         abase##C = reinterpret_cast<const uint4 *>(a + (size_t)r * FCH_K + k0) + scol;            \
     }
     FC_MAP(0) FC_MAP(1) FC_MAP(2) FC_MAP(3)     // chunk C belongs to row tile C; tiles >= MTR are never touched
 #undef FC_MAP
-#define FC_LD1(S, C, SLAB) if constexpr ((C) < MTR) S##C = abase##C[(SLAB) * 8];
-#define FC_WR1(S, C, BUF) if constexpr ((C) < MTR) lds[BUF][sdst##C] = S##C;
+    constexpr int NCHUNK = MTR * 4 / WAVES;                 // 16-byte staging chunks per thread and slab
+#define FC_LD1(S, C, SLAB) if constexpr ((C) < NCHUNK) S##C = abase##C[(SLAB) * 8];
+#define FC_WR1(S, C, BUF) if constexpr ((C) < NCHUNK) lds[BUF][sdst##C] = S##C;
 #define FC_LOAD(S, SLAB) { FC_LD1(S, 0, SLAB) FC_LD1(S, 1, SLAB) FC_LD1(S, 2, SLAB) FC_LD1(S, 3, SLAB) }
 #define FC_WRITE(S, BUF) { FC_WR1(S, 0, BUF) FC_WR1(S, 1, BUF) FC_WR1(S, 2, BUF) FC_WR1(S, 3, BUF) }
     // A-fragment read offsets (16-byte units) inside a buffer, per row tile, for k-step 0 of a slab
@@ -680,6 +692,15 @@ __device__ __forceinline__ void fc_f16_tile(const _Float16 *__restrict__ a, cons
     }
 }
 
+// Small batches: one wave per block (see WAVES).  Launch with 32 blocks of 64 threads per 32 rows.
+__global__ __launch_bounds__(64) void fc_f16_small_kernel(const _Float16 *__restrict__ a, const _Float16 *__restrict__ wp,
+                                                          float *__restrict__ part,
+                                                          const int32_t *__restrict__ count_ptr, int n_fixed,
+                                                          int max_rows) {
+    __shared__ __attribute__((aligned(16))) uint4 lds[3][FCH_BM * 8];
+    fc_f16_tile<1, 0, 8, 2, 1>(a, wp, part, batch_count16(count_ptr, n_fixed), max_rows, lds);
+}
+
 // ABLATE (timing experiments only): 1 no A global loads, 2 no A-fragment LDS reads, 4 no weight loads,
 // 8 no barriers, 16 no staging writes.
 template <int ABLATE = 0, int BR = 8, int NSET = 2>
@@ -767,12 +788,22 @@ constexpr size_t conv_lds_bytes(int ih, int iw, int nb) {
     int npos = 2 + nb * ih * (iw + 2) + 1, m = nb * (ih + 1) * (iw + 1);
     return (size_t)(npos > m ? npos : m) * CONV_RS * 16;
 }
+// Engines of at most kSmallBatch slots (single searches, small tournaments) are latency-bound: one board
+// per block gives every wave a third of the tiles and three to four times as many blocks.
+constexpr int kSmallBatch = 128;
+constexpr size_t C2S_LDS = conv_lds_bytes(7, 8, 1), C4S_LDS = conv_lds_bytes(8, 9, 1);
 constexpr size_t C2H_LDS = conv_lds_bytes(7, 8, C2H_NB);
 constexpr size_t C4H_LDS = conv_rows_lds_bytes(8, 9, C4H_NB);
 
 hipError_t prepare_net_kernels_f16() {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mid_f16_kernel<7, 8, C2H_NB, 2, 4, 4, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C2H_LDS);
+    if (err != hipSuccess) return err;
+    err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mid_f16_kernel<7, 8, 1, 2, 8, 4, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C2S_LDS);
+    if (err != hipSuccess) return err;
+    err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mid_f16_kernel<8, 9, 1, 2, 8, 4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C4S_LDS);
     if (err != hipSuccess) return err;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rows_f16_kernel<8, 9, C4H_NB, 1, 4, 8>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)C4H_LDS);
@@ -794,14 +825,29 @@ void launch_net_stage_f16(hipStream_t st, int stage, const NetWeights &w, const 
     case NET_CONV0:
         break;      // fused into the first 128->128 layer below
     case NET_CONV2:
+        if (n_max <= kSmallBatch) {
+            conv_mid_f16_kernel<7, 8, 1, 2, 8, 4, true><<<n_max, 256, C2S_LDS, st>>>(
+                nullptr, (const _Float16 *)w.conv2_wh, w.conv2_b, a2, count_ptr, n_max, side, w.conv0_w, w.conv0_b);
+            break;
+        }
         conv_mid_f16_kernel<7, 8, C2H_NB, 2, 4, 4, true><<<cdiv16(n_max, C2H_NB), 256, C2H_LDS, st>>>(
             nullptr, (const _Float16 *)w.conv2_wh, w.conv2_b, a2, count_ptr, n_max, side, w.conv0_w, w.conv0_b);
         break;
     case NET_CONV4:
+        if (n_max <= kSmallBatch) {
+            conv_mid_f16_kernel<8, 9, 1, 2, 8, 4><<<n_max, 256, C4S_LDS, st>>>(
+                a2, (const _Float16 *)w.conv4_wh, w.conv4_b, a3, count_ptr, n_max);
+            break;
+        }
         conv_rows_f16_kernel<8, 9, C4H_NB, 1, 4, 8><<<cdiv16(n_max, C4H_NB), 256, C4H_LDS, st>>>(
             a2, (const _Float16 *)w.conv4_wh, w.conv4_b, a3, count_ptr, n_max);
         break;
     case NET_FC: {
+        if (n_max <= kSmallBatch) {
+            fc_f16_small_kernel<<<32 * cdiv16(n_max, 32), 64, 0, st>>>(a3, (const _Float16 *)w.fc_wh, b.fcpart, count_ptr,
+                                                                    n_max, b.max_rows);
+            break;
+        }
         int groups = cdiv16(cdiv16(n_max, FCH_BM), 32);      // 32 row blocks per group of 256 blocks
         fc_f16_kernel<0, 8, 2><<<256 * groups, 256, 0, st>>>(a3, (const _Float16 *)w.fc_wh, b.fcpart, count_ptr, n_max,
                                                     b.max_rows);
