@@ -116,7 +116,19 @@ def main():
     use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        # RCCL prints a version banner on stdout when its first communicator comes up; stdout is
+        # reserved for the one JSON line, so the banner goes to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=device)
+            dist.barrier()
+            torch.cuda.synchronize(device)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     G = args.games
     cache_line = not args.no_eval_cache_line
