@@ -31,7 +31,8 @@ class SearchParams(C.Structure):
                 ("weight_set", C.c_int32), ("flags", C.c_int32), ("rng_move_index", C.c_int32),
                 ("rng_game_base", C.c_int32), ("weight_set_colour2_plus1", C.c_int32),
                 ("c_puct", C.c_double), ("dirichlet_alpha", C.c_double),
-                ("dirichlet_eps", C.c_double), ("seed", C.c_uint64)]
+                ("dirichlet_eps", C.c_double), ("seed", C.c_uint64),
+                ("side_of_colour", C.c_int32 * 2), ("round_limit", C.c_int64)]
 
 
 class RoundStats(C.Structure):
@@ -61,7 +62,7 @@ SIGNATURES = {
     "nnb_ucb_scores": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_double, _P]),
     "nnb_net_forward": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P, _P, _P, _P, _P]),
     "nnb_net_forward_planes": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P, _P, _P]),
-    "nnb_search": (C.c_int, [_P, _P, C.POINTER(SearchParams), C.c_int32, _P, _P, _P, _P, _P, _P,
+    "nnb_search": (C.c_int, [_P, _P, C.POINTER(SearchParams), C.c_int32, _P, _P, _P, _P, _P, _P, _P,
                              C.POINTER(RoundStats)]),
     "nnb_dirichlet_noise": (C.c_int, [_P, C.c_int32, C.c_uint64, _P, _P, _P, C.c_double, _P]),
     "nnb_selfplay_round": (C.c_int, [_P, _P, C.POINTER(SearchParams), C.c_int32, C.c_int32, _P, _P,

@@ -25,6 +25,7 @@ from .network import Connect4Net
 logger = logging.getLogger(__name__)
 
 MODEL_PATH = "nnbattle/agents/alphazero/model/alphazero_model_final.pth"   # utils.py:31
+DEFAULT_PRECISION = "f32"
 
 
 class Agent(ABC):
@@ -66,6 +67,10 @@ class AlphaZeroAgent(Agent):
         self.logger = self.__class__.logger
         self.evaluator = "net"          # fixed evaluators ("const", "hash_q8", "hash_f32") for parity runs
         self.eval_cache = False         # True: a game does not send one position to the network twice (same moves)
+        # arithmetic of the network's conv / linear layers on the device (engine.PRECISIONS): "f32s" is
+        # float32-faithful (the reference computes in float32, network.py:43-50), "f16" rounds the
+        # operands to half and runs three times as fast, "f32" is the exact-FMA matrix path
+        self.precision = DEFAULT_PRECISION
         self._engine = None
         self._engine_key = None
         self._weights_stamp = None
@@ -81,12 +86,14 @@ class AlphaZeroAgent(Agent):
         """The device engine sized for this agent (created on first use, re-created if the
         simulation count or the requested game count grows)."""
         from .engine import Engine
-        key = (max(int(max_games), 1), max(int(self.num_simulations), int(max_sims), 1), bool(self.eval_cache))
+        key = (max(int(max_games), 1), max(int(self.num_simulations), int(max_sims), 1), bool(self.eval_cache),
+               str(self.precision))
         if (self._engine is None or self._engine_key[0] < key[0] or self._engine_key[1] < key[1]
-                or self._engine_key[2] != key[2]):
+                or self._engine_key[2:] != key[2:]):
             if self._engine is not None:
                 self._engine.close()
-            self._engine = Engine(max_games=key[0], max_sims=key[1], eval_cache_slots=2048 if key[2] else 0)
+            self._engine = Engine(max_games=key[0], max_sims=key[1], eval_cache_slots=2048 if key[2] else 0,
+                                  precision=key[3])
             self._engine_key = key
             self._weights_stamp = None
         if self.evaluator == "net":
@@ -146,16 +153,19 @@ class AlphaZeroAgent(Agent):
         Returns (selected column, columns that got a child, visit distribution) exactly as
         the reference does: the most visited root child with the lowest column on ties, and
         visits/total as a FloatTensor[7] on self.device.  Like the reference, the colour
-        placed during descent and the side the network looks from are taken from
-        `env.current_player` and `self.current_player` respectively; callers keep the two
-        equal (train_alpha_zero.py:38,45).
+        placed during descent is `env.current_player` (agent_code.py:167,176) and the side
+        the network looks from is `self.current_player` (agent_code.py:85-87); the two are
+        handed to the engine separately.  self_play keeps them equal
+        (train_alpha_zero.py:38,45); run_tournament.py:21-22 never updates the agent's.
         """
         eng = self.engine(1, num_simulations)
         b1, b2 = board_to_bits(np.asarray(env.board))
         params = eng.params(num_simulations, self.c_puct, evaluator=self.evaluator, mode="compat",
                             eval_cache=self.eval_cache)
         visits, action, _rootv, _stats = eng.search(np.array([[b1, b2]], dtype=np.uint64),
-                                                    np.array([env.current_player], dtype=np.int8), params)
+                                                    np.array([env.current_player], dtype=np.int8), params,
+                                                    side_players=np.array([2 if self.current_player == 2 else 1],
+                                                                          dtype=np.int8))
         if int(action[0]) < 0:
             logger.error("No actions available after MCTS simulations.")
             return None, [], []

@@ -43,7 +43,9 @@ struct EngineDev {
     double  *log_table;         // [max_sims + 8]  log(n + 1), filled by the host's libm
 
     u64     *root_boards;       // [G][2] colour boards of each root
-    int8_t  *root_player;       // [G]
+    int8_t  *root_player;       // [G] colour to move at the root (env.current_player, agent_code.py:167)
+    int8_t  *root_side;         // [G] colour the leaf planes are encoded from (agent.current_player,
+                                //     agent_code.py:85-87); 0 = SearchDev::side of the mover, else the mover
     int32_t *active;            // [G] 1 while the game / search is live
     int32_t *n_nodes;           // [G]
     int32_t *sims_done;         // [G]
@@ -99,6 +101,7 @@ struct SearchDev {
     int32_t rng_move_index;
     int32_t rng_game_base;
     int32_t wset[2];            // weight set searching for colour 1 / colour 2
+    int32_t side[2];            // COMPAT: colour the planes are encoded from while colour 1 / 2 moves; 0 = the mover
     double  c_puct;
     double  dirichlet_alpha;
     double  dirichlet_eps;

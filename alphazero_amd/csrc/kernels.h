@@ -33,7 +33,7 @@ void launch_readout(hipStream_t st, const EngineDev &e, const SearchDev &p, int3
 void launch_selfplay_init(hipStream_t st, const EngineDev &e, const RoundDev &round);
 void launch_turnover(hipStream_t st, const EngineDev &e, const SearchDev &p, const RoundDev &round, int make_noise);
 void launch_search_init(hipStream_t st, const EngineDev &e, const u64 *boards, const int8_t *players,
-                        int game_base, const float *root_noise);
+                        const int8_t *sides, int game_base, const float *root_noise);
 void launch_dirichlet_noise(hipStream_t st, int n, u64 seed, const int32_t *game_ids, const int32_t *move_index,
                             const uint8_t *legal, double alpha, float *out);
 void launch_stats_reduce(hipStream_t st, const EngineDev &e);

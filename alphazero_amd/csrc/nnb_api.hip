@@ -39,6 +39,7 @@ int fail(int code, const char *fmt, ...) {
 
 constexpr size_t kAlign = 256;
 constexpr int kMaxSims = 9000;           // first_child is 16 bit: 1 + 7*sims <= 65535
+constexpr size_t kFusedLdsLimit = 160 * 1024;   // LDS of one CU
 constexpr int kProfClasses = 7;
 constexpr int kProfSamples = 16;         // event pairs per class per drain
 
@@ -83,17 +84,17 @@ struct nnb_engine {
 
 namespace {
 
-// Returns the size of the leading part of the workspace that must start out zeroed (search state);
-// the activation and weight areas behind it are fully overwritten before they are read.
-size_t carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std::vector<NetWeights> &w) {
-    const size_t G = cfg.max_games;
-    const size_t cap = 1 + 7 * (size_t)cfg.max_sims;
-    d.max_games = cfg.max_games; d.pool_cap = (int32_t)cap; d.max_sims = cfg.max_sims; d.n_games = 0;
+// Search state of G concurrent games / roots whose per-game node pools in device memory hold `cap`
+// nodes (the fused tree kernel keeps its pool in LDS and only hands the root and its children over,
+// so 8 suffice for it), with a log table for up to max_sims simulations.
+void carve_state(size_t G, size_t cap, int max_sims, int cache_slots, Carver &c, EngineDev &d) {
+    d.max_games = (int32_t)G; d.pool_cap = (int32_t)cap; d.max_sims = max_sims; d.n_games = 0;
     d.nodes = c.take<Node>(G * cap);
     d.prior = c.take<float>(G * cap);
-    d.log_table = c.take<double>(cfg.max_sims + 8);
+    d.log_table = c.take<double>(max_sims + 8);
     d.root_boards = c.take<u64>(2 * G);
     d.root_player = c.take<int8_t>(G);
+    d.root_side = c.take<int8_t>(G);
     d.active = c.take<int32_t>(G);
     d.n_nodes = c.take<int32_t>(G);
     d.sims_done = c.take<int32_t>(G);
@@ -116,8 +117,15 @@ size_t carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std:
     d.stats64 = c.take<unsigned long long>(32);
     d.cache_gen = c.take<uint32_t>(G);
     d.pend_key = c.take<u64>(2 * G);
-    d.cache_slots = cfg.eval_cache_slots;
-    d.cache = cfg.eval_cache_slots > 0 ? c.take<CacheEntry>(G * (size_t)cfg.eval_cache_slots) : nullptr;
+    d.cache_slots = cache_slots;
+    d.cache = cache_slots > 0 ? c.take<CacheEntry>(G * (size_t)cache_slots) : nullptr;
+}
+
+// Returns the size of the leading part of the workspace that must start out zeroed (search state);
+// the activation and weight areas behind it are fully overwritten before they are read.
+size_t carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std::vector<NetWeights> &w) {
+    const size_t G = cfg.max_games;
+    carve_state(G, 1 + 7 * (size_t)cfg.max_sims, cfg.max_sims, cfg.eval_cache_slots, c, d);
     c.take<unsigned char>(kAlign);
     const size_t state_bytes = c.off;
     if (cfg.net_precision == NNB_NET_F32) {
@@ -212,6 +220,7 @@ SearchDev to_dev(const nnb_search_params &p) {
     SearchDev s;
     s.mode = p.mode; s.evaluator = p.evaluator; s.sims = p.sims; s.flags = p.flags; s.rng_move_index = p.rng_move_index; s.rng_game_base = p.rng_game_base;
     s.wset[0] = p.weight_set; s.wset[1] = p.weight_set_colour2_plus1 > 0 ? p.weight_set_colour2_plus1 - 1 : p.weight_set;
+    s.side[0] = p.side_of_colour[0]; s.side[1] = p.side_of_colour[1];
     s.c_puct = p.c_puct; s.dirichlet_alpha = p.dirichlet_alpha; s.dirichlet_eps = p.dirichlet_eps;
     s.seed = p.seed;
     return s;
@@ -248,6 +257,10 @@ int check_params(nnb_engine *e, const nnb_search_params *p, int n) {
         }
     }
     if (!(p->c_puct >= 0.0) || !std::isfinite(p->c_puct)) return fail(NNB_ERR_ARG, "c_puct must be finite and >= 0");
+    if (p->round_limit < 0) return fail(NNB_ERR_ARG, "round_limit must be >= 0");
+    for (int k = 0; k < 2; ++k)
+        if (p->side_of_colour[k] < 0 || p->side_of_colour[k] > 2)
+            return fail(NNB_ERR_ARG, "side_of_colour[%d] = %d is not 0 (the mover), 1 or 2", k, p->side_of_colour[k]);
     return NNB_OK;
 }
 
@@ -351,16 +364,19 @@ int run_move(nnb_engine *e, hipStream_t st, const nnb_search_params &p, int32_t 
         make_noise = 1;
     }
     launch_tree_init(st, d, sd, make_noise, selfplay);
-    if (p.evaluator == NNB_EVAL_NET || (p.flags & NNB_FLAG_LOCKSTEP)) {
+    // the fused kernel keeps the node pool of this search in LDS; a search too long for that runs the
+    // lock-step path instead (same results), except random rollouts, which only the fused kernel draws
+    const size_t pool_nodes = 1 + 7 * (size_t)p.sims;
+    const size_t lds = pool_nodes * sizeof(Node) + (az ? pool_nodes * sizeof(float) : (size_t)(p.sims + 2) * sizeof(double));
+    const bool fits_lds = lds <= kFusedLdsLimit;
+    if (p.evaluator == NNB_EVAL_NET || (p.flags & NNB_FLAG_LOCKSTEP) || (!fits_lds && p.evaluator != NNB_EVAL_ROLLOUT)) {
         const StepPlan plan = make_step_plan(e, p, sd);
         for (int s = 0; s <= p.sims; ++s) lockstep_step(e, st, p, sd, plan, s & 1, s < p.sims);
         *steps += p.sims;
     } else {
-        size_t lds = (size_t)d.pool_cap * sizeof(Node) +
-                     (az ? (size_t)d.pool_cap * sizeof(float) : (size_t)(p.sims + 2) * sizeof(double));
-        if (lds > 160 * 1024)
-            return fail(NNB_ERR_ARG, "sims = %d needs %zu bytes of LDS for the fused tree kernel (limit 163840)",
-                        p.sims, lds);
+        if (!fits_lds)
+            return fail(NNB_ERR_ARG, "sims = %d needs %zu bytes of LDS for the fused tree kernel (limit %zu)",
+                        p.sims, lds, kFusedLdsLimit);
         if (lds > e->fused_lds_prepared) {
             HIP_TRY(prepare_tree_fused(lds));
             e->fused_lds_prepared = lds;
@@ -568,14 +584,14 @@ int nnb_net_forward_planes(nnb_engine *e, int weight_set, void *stream, int32_t 
 }
 
 int nnb_search(nnb_engine *e, void *stream, const nnb_search_params *params, int32_t n,
-               const uint64_t *root_colour_boards, const int8_t *root_players, const float *root_noise,
-               int32_t *visits_out, int8_t *action_out, double *root_value_out, nnb_round_stats *stats_out) {
+               const uint64_t *root_colour_boards, const int8_t *root_players, const int8_t *side_players,
+               const float *root_noise, int32_t *visits_out, int8_t *action_out, double *root_value_out, nnb_round_stats *stats_out) {
     int rc = check_params(e, params, n);
     if (rc) return rc;
     if (!root_colour_boards || !root_players) return fail(NNB_ERR_ARG, "root boards / players is null");
     hipStream_t st = static_cast<hipStream_t>(stream);
     e->dev.n_games = n;
-    launch_search_init(st, e->dev, reinterpret_cast<const u64 *>(root_colour_boards), root_players,
+    launch_search_init(st, e->dev, reinterpret_cast<const u64 *>(root_colour_boards), root_players, side_players,
                        params->rng_game_base, root_noise);
     long long steps = 0;
     rc = run_move(e, st, *params, visits_out, action_out, root_value_out, nullptr, root_noise != nullptr, &steps);
@@ -588,6 +604,10 @@ int nnb_selfplay_round(nnb_engine *e, void *stream, const nnb_search_params *par
                        nnb_trajectory *trajectories_out, nnb_round_stats *stats_out) {
     if (!e) return fail(NNB_ERR_ARG, "engine is null");
     if (n_games < 0) return fail(NNB_ERR_ARG, "n_games < 0");
+    if (n_games == 0) {                                  // nothing to play: a no-op like the other entry points
+        if (stats_out) memset(stats_out, 0, sizeof *stats_out);
+        return NNB_OK;
+    }
     const int slots = n_games < e->cfg.max_games ? n_games : e->cfg.max_games;
     int rc = check_params(e, params, slots);
     if (rc) return rc;
@@ -621,7 +641,8 @@ int nnb_selfplay_round(nnb_engine *e, void *stream, const nnb_search_params *par
         constexpr int kChunk = 64;
         e->prof_stride = kChunk / kProfSamples + 1;
         launch_tree_init(st, e->dev, sd, make_noise, 1);
-        const long long max_steps = ((long long)n_games / (slots > 0 ? slots : 1) + 2) * (kMaxPlies + 1) * (params->sims + 1);
+        long long max_steps = ((long long)n_games / (slots > 0 ? slots : 1) + 2) * (kMaxPlies + 1) * (params->sims + 1);
+        if (params->round_limit > 0 && params->round_limit < max_steps) max_steps = params->round_limit;
         while (live > 0 && steps < max_steps) {
             for (int k = 0; k < kChunk; ++k, ++steps) {
                 // with root noise to draw the turnover is a launch of its own, otherwise part of the step
@@ -635,10 +656,15 @@ int nnb_selfplay_round(nnb_engine *e, void *stream, const nnb_search_params *par
             live = e->host_counters[0];
         }
         rounds = (steps + params->sims) / (params->sims + 1);
-        return collect_stats(e, st, stats_out, steps, rounds, n_games);
+        rc = collect_stats(e, st, stats_out, steps, rounds, n_games);
+        if (rc) return rc;
+        if (live > 0)
+            return fail(NNB_ERR_STATE, "self-play stopped after %lld lock-step rounds with %d games unfinished "
+                        "(their records have result = 2)", steps, live);
+        return NNB_OK;
     }
     const long long max_rounds = ((long long)n_games / (slots > 0 ? slots : 1) + 2) * (kMaxPlies + 1);
-    while (live > 0 && rounds < max_rounds) {
+    while (live > 0 && rounds < max_rounds && !(params->round_limit > 0 && steps >= params->round_limit)) {
         HIP_TRY(hipMemsetAsync(e->dev.counters, 0, 16 * sizeof(int32_t), st));
         rc = run_move(e, st, *params, nullptr, nullptr, nullptr, &round, false, &steps);
         if (rc) return rc;
@@ -648,7 +674,12 @@ int nnb_selfplay_round(nnb_engine *e, void *stream, const nnb_search_params *par
         live = e->host_counters[0];
         ++rounds;
     }
-    return collect_stats(e, st, stats_out, steps, rounds, n_games);
+    rc = collect_stats(e, st, stats_out, steps, rounds, n_games);
+    if (rc) return rc;
+    if (live > 0)
+        return fail(NNB_ERR_STATE, "self-play stopped after %lld move rounds with %d games unfinished "
+                    "(their records have result = 2)", rounds, live);
+    return NNB_OK;
 }
 
 int nnb_dirichlet_noise(void *stream, int32_t n, uint64_t seed, const int32_t *game_ids, const int32_t *move_indices,

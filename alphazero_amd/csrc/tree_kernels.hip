@@ -159,6 +159,14 @@ __device__ __forceinline__ void wave_mem_sync() {
 // two-set arena can be checked bit for bit without networks.
 __device__ __forceinline__ u64 set_mix(int wset) { return (u64)wset * 0xD6E8FEB86659FD93ULL; }
 
+// The colour whose stones fill the first input plane of a COMPAT leaf (agent.current_player,
+// agent_code.py:85-87): the caller's per-root choice, else the round's per-colour choice, else the mover.
+__device__ __forceinline__ int view_side(const EngineDev &e, const SearchDev &p, int g, int player) {
+    int s = e.root_side[g];
+    if (s == 0) s = p.side[player - 1];
+    return s == 0 ? player : s;
+}
+
 __device__ __forceinline__ double fixed_eval(int evaluator, u64 me, u64 opp) {
     if (evaluator == NNB_EVAL_HASH_Q8) return c4::hash_value_q8(me, opp);
     if (evaluator == NNB_EVAL_HASH_F32) return c4::hash_value_f32(me, opp);
@@ -556,10 +564,11 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
             ++sims_done; ++term_hits; ++spot;
             continue;
         }
-        // COMPAT: the leaf is encoded from the root mover's side at every depth
-        // (agent_code.py:85); AZ: from the side to move at the leaf
-        leaf_me = mover == 1 ? c1 : c2;
-        leaf_opp = mover == 1 ? c2 : c1;
+        // COMPAT: the leaf is encoded from the agent's side at every depth (agent_code.py:85;
+        // `mover` is still the root mover here); AZ: from the side to move at the leaf
+        const int view = AZ ? mover : view_side(e, p, g, player);
+        leaf_me = view == 1 ? c1 : c2;
+        leaf_opp = view == 1 ? c2 : c1;
         if constexpr (CACHE) {
             const u64 kopp = leaf_opp | ((u64)batch << 63);      // the two networks of an arena do not share entries
             const CacheEntry *ce = table + (c4::mix64(leaf_me, kopp) & (u64)(e.cache_slots - 1));
@@ -624,8 +633,8 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
 // ---------------------------------------------------------------------------
 // K2, fused form (fixed evaluators: CONST / HASH / ROLLOUT): the whole search of one move
 // in one launch, the node pool resident in LDS.  One 64-thread block (one wavefront) per
-// game.  Dynamic LDS: pool_cap*16 bytes of nodes, then (COMPAT) the log table of sims+2
-// doubles or (AZ) pool_cap float priors.
+// game.  Dynamic LDS: (1 + 7*sims)*16 bytes of nodes, then (COMPAT) the log table of sims+2
+// doubles or (AZ) one float prior per node.
 // ---------------------------------------------------------------------------
 template <bool AZ>
 __global__ __launch_bounds__(64) void tree_fused_kernel(EngineDev e, SearchDev p) {
@@ -634,9 +643,10 @@ __global__ __launch_bounds__(64) void tree_fused_kernel(EngineDev e, SearchDev p
     const int g = blockIdx.x;
     if (g >= e.n_games) return;
     if (!e.active[g]) return;
+    const size_t pool_nodes = 1 + 7 * (size_t)p.sims;          // nodes this search can create
     Node *pool = reinterpret_cast<Node *>(smem);
-    double *logt = reinterpret_cast<double *>(smem + (size_t)e.pool_cap * sizeof(Node));
-    float *prior = reinterpret_cast<float *>(smem + (size_t)e.pool_cap * sizeof(Node));
+    double *logt = reinterpret_cast<double *>(smem + pool_nodes * sizeof(Node));
+    float *prior = reinterpret_cast<float *>(smem + pool_nodes * sizeof(Node));
     if (!AZ)
         for (int i = lane; i < p.sims + 2; i += 64) logt[i] = e.log_table[i];
     if (lane == 0) {
@@ -650,6 +660,7 @@ __global__ __launch_bounds__(64) void tree_fused_kernel(EngineDev e, SearchDev p
     const u64 r1 = e.root_boards[2 * g], r2 = e.root_boards[2 * g + 1];
     const uint32_t game = (uint32_t)e.game_id[g], move = (uint32_t)e.move_index[g];
     const u64 smix = set_mix(p.wset[player - 1]);
+    const int view = view_side(e, p, g, player);
     int n_nodes = 1, depth_sum = 0, term_hits = 0, leaves = 0;
     for (int s = 0; s < p.sims; ++s) {
         int mypath;
@@ -686,7 +697,7 @@ __global__ __launch_bounds__(64) void tree_fused_kernel(EngineDev e, SearchDev p
                     int res = rollout(d.c1, d.c2, player, p.seed, game, move, (uint32_t)s);
                     v = res == 1 ? -1.0 : (res == -1 ? 1.0 : 0.0);
                 } else {
-                    v = fixed_eval(p.evaluator, (player == 1 ? d.c1 : d.c2) ^ smix, player == 1 ? d.c2 : d.c1);
+                    v = fixed_eval(p.evaluator, (view == 1 ? d.c1 : d.c2) ^ smix, view == 1 ? d.c2 : d.c1);
                 }
                 ++leaves;
             }
@@ -731,6 +742,7 @@ __device__ bool seat_game(const EngineDev &e, const RoundDev &r, int g, int j) {
     }
     e.root_boards[2 * g] = b1; e.root_boards[2 * g + 1] = b2;
     e.root_player[g] = (int8_t)player;
+    e.root_side[g] = 0;                                       // self-play: SearchDev::side decides
     e.ply[g] = 0;
     e.game_id[g] = r.first_game_id + j;
     e.traj_index[g] = j;
@@ -838,13 +850,14 @@ __global__ void selfplay_init_kernel(EngineDev e, RoundDev round) {
 
 // Search-only set-up: caller-supplied roots, every root searched.
 __global__ void search_init_kernel(EngineDev e, const u64 *__restrict__ boards,
-                                   const int8_t *__restrict__ players, int game_base,
-                                   const float *__restrict__ root_noise) {
+                                   const int8_t *__restrict__ players, const int8_t *__restrict__ sides,
+                                   int game_base, const float *__restrict__ root_noise) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= e.n_games) return;
     const u64 b1 = boards[2 * g] & c4::kBoardMask, b2 = boards[2 * g + 1] & c4::kBoardMask & ~b1;
     e.root_boards[2 * g] = b1; e.root_boards[2 * g + 1] = b2;
     e.root_player[g] = players[g] == 2 ? 2 : 1;
+    e.root_side[g] = sides ? (sides[g] == 2 ? 2 : 1) : 0;
     e.cache_gen[g] += 1;
     e.active[g] = 1;
     e.ply[g] = 0;
@@ -1127,8 +1140,8 @@ void launch_selfplay_init(hipStream_t st, const EngineDev &e, const RoundDev &ro
 }
 
 void launch_search_init(hipStream_t st, const EngineDev &e, const u64 *boards, const int8_t *players,
-                        int game_base, const float *root_noise) {
-    search_init_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, boards, players, game_base, root_noise);
+                        const int8_t *sides, int game_base, const float *root_noise) {
+    search_init_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, boards, players, sides, game_base, root_noise);
 }
 
 void launch_fixed_eval(hipStream_t st, const EngineDev &e, const SearchDev &p, int batch, int parity) {

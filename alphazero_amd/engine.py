@@ -96,7 +96,8 @@ class Engine:
                dirichlet_alpha: float = 0.0, dirichlet_eps: float = 0.0, seed: int = 0,
                lockstep: bool = False, rng_move_index: int = 0, rng_game_base: int = 0,
                weight_set_colour2: Optional[int] = None, separate_heads: bool = False,
-               sync_moves: bool = False, eval_cache: bool = False) -> SearchParams:
+               sync_moves: bool = False, eval_cache: bool = False, side_of_colour=(0, 0),
+               round_limit: int = 0) -> SearchParams:
         ev = EVALUATORS[evaluator] if isinstance(evaluator, str) else int(evaluator)
         md = MODES[mode] if isinstance(mode, str) else int(mode)
         return SearchParams(md, ev, int(sims), int(weight_set), int(bool(lockstep)) | (2 if separate_heads else 0) | (4 if sync_moves else 0)
@@ -104,7 +105,8 @@ class Engine:
                             int(rng_move_index),
                             int(rng_game_base), 0 if weight_set_colour2 is None else int(weight_set_colour2) + 1,
                             float(c_puct), float(dirichlet_alpha), float(dirichlet_eps),
-                            int(seed))
+                            int(seed), (C.c_int32 * 2)(int(side_of_colour[0]), int(side_of_colour[1])),
+                            int(round_limit))
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state_dict, weight_set: int = 0):
@@ -199,9 +201,11 @@ class Engine:
         return logp, value
 
     # ------------------------------------------------------------------ K2 / K7
-    def search(self, colour_boards, players, params: SearchParams, root_noise=None):
+    def search(self, colour_boards, players, params: SearchParams, root_noise=None, side_players=None):
         """One search per root.  Returns (visits int32[n,7], action int8[n], root_value f64[n], stats).
-        root_noise: optional float32 [n,7] mixed into the root priors (AZ mode)."""
+        players: colour to move at each root (the colour the reference rule places during descent).
+        side_players: colour the network looks from (agent.current_player, agent_code.py:85-87);
+        None = the mover.  root_noise: optional float32 [n,7] mixed into the root priors (AZ mode)."""
         b = self._dev(np.asarray(colour_boards, dtype=np.uint64).reshape(-1, 2), torch.int64)
         n = b.shape[0]
         pl = self._dev(np.asarray(players, dtype=np.int8), torch.int8)
@@ -209,12 +213,14 @@ class Engine:
         action = torch.empty((n,), dtype=torch.int8, device=self.device)
         rootv = torch.empty((n,), dtype=torch.float64, device=self.device)
         stats = RoundStats()
-        noise = None
+        noise = sides = None
         if root_noise is not None:
             noise = self._dev(np.asarray(root_noise, dtype=np.float32).reshape(n, 7), torch.float32)
+        if side_players is not None:
+            sides = self._dev(np.asarray(side_players, dtype=np.int8).reshape(n), torch.int8)
         with torch.cuda.device(self.device):
             check(self.lib.nnb_search(self.handle, self._stream(), C.byref(params), n, _ptr(b), _ptr(pl),
-                                      _ptr(noise), _ptr(visits), _ptr(action), _ptr(rootv), C.byref(stats)),
+                                      _ptr(sides), _ptr(noise), _ptr(visits), _ptr(action), _ptr(rootv), C.byref(stats)),
                   "nnb_search")
         return visits.cpu().numpy(), action.cpu().numpy(), rootv.cpu().numpy(), stats.as_dict()
 

@@ -37,15 +37,18 @@ def _column(move):
     return None if move is None else int(move)
 
 
-def play_match(agents, names, game, starter: int):
-    """One game; returns the winning agent's name or 'draws'."""
+def play_match(agents, names, game, starter: int, keep_agent_sides: bool = False):
+    """One game; returns the winning agent's name or 'draws'.  An AlphaZeroAgent encodes positions
+    from its `current_player` attribute (agent_code.py:85-87): by default that is set to the colour
+    the agent plays, as self_play does; keep_agent_sides=True leaves it alone, which is what
+    run_tournament.py:21-22 does (the attribute then keeps whatever the caller last gave it)."""
     game.reset()
     seat = starter
     while not game.is_terminal_node():
         agent = agents[seat]
         piece = PLAYER_PIECE if seat == 0 else AI_PIECE
         game.current_player = piece
-        if hasattr(agent, "current_player"):
+        if hasattr(agent, "current_player") and not keep_agent_sides:
             agent.current_player = piece
         col = _column(agent.select_move(game))
         if col is None or not game.is_valid_location(col):
@@ -65,21 +68,23 @@ def arena_capable(agents) -> bool:
         return False
     a, b = agents
     return (a.num_simulations == b.num_simulations and a.c_puct == b.c_puct and a.evaluator == b.evaluator
-            and a.num_simulations >= 2)
+            and a.precision == b.precision and a.num_simulations >= 2)
 
 
-def arena(agents, num_games: int, engine=None, first_game_id: int = 0):
+def arena(agents, num_games: int, engine=None, first_game_id: int = 0, keep_agent_sides: bool = False):
     """Plays `num_games` games between two AlphaZeroAgents on the GPU, all games at once.
 
     agents[0] plays colour 1 and agents[1] colour 2; game i is started by agents[i % 2]
     (run_tournament.py:17-19).  Returns (wins of agents[0], wins of agents[1], draws, records)
     with `records` the engine's trajectory records (engine.TRAJECTORY_DTYPE).  A game that
     ends with a full board, or in which the mover has no move, is a draw
-    (run_tournament.py:30-35).
+    (run_tournament.py:30-35).  Each search encodes its leaves from the searching agent's own colour;
+    with keep_agent_sides=True from that agent's `current_player` attribute as it stands
+    (run_tournament.py:21-22 never updates it).
     """
     from .engine import TRAJECTORY_DTYPE, Engine, trajectories_to_numpy
     if not arena_capable(agents):
-        raise ValueError("arena needs two AlphaZeroAgents with equal num_simulations, c_puct and evaluator")
+        raise ValueError("arena needs two AlphaZeroAgents with equal num_simulations, c_puct, evaluator and precision")
     a, b = agents
     for ag in agents:
         if ag.load_model_flag and not ag.model_loaded:
@@ -87,13 +92,14 @@ def arena(agents, num_games: int, engine=None, first_game_id: int = 0):
     n_round = min(int(num_games), ARENA_CONCURRENT_GAMES)
     own = engine is None
     if own:
-        engine = Engine(max_games=max(n_round, 1), max_sims=a.num_simulations, n_weight_sets=2)
+        engine = Engine(max_games=max(n_round, 1), max_sims=a.num_simulations, n_weight_sets=2, precision=a.precision)
     try:
         if a.evaluator == "net":
             engine.load_state_dict(a.model.state_dict(), weight_set=0)
             engine.load_state_dict(b.model.state_dict(), weight_set=1)
+        sides = (2 if a.current_player == 2 else 1, 2 if b.current_player == 2 else 1) if keep_agent_sides else (0, 0)
         params = engine.params(a.num_simulations, a.c_puct, evaluator=a.evaluator, mode="compat", weight_set=0,
-                               weight_set_colour2=1)
+                               weight_set_colour2=1, side_of_colour=sides)
         n = int(num_games)
         records = np.zeros(0, dtype=TRAJECTORY_DTYPE)
         if n > 0:
@@ -121,7 +127,7 @@ def mixed_arena_capable(agents) -> bool:
         a.num_simulations >= 2 for a in agents if isinstance(a, AlphaZeroAgent))
 
 
-def mixed_arena(agents, num_games: int):
+def mixed_arena(agents, num_games: int, keep_agent_sides: bool = False):
     """AlphaZeroAgent against MinimaxAgent, all games of the tournament advanced together: at every
     ply the positions where the minimax agent is to move go through one nnb_minimax call and those
     where the AlphaZero agent is to move through batched searches; moves are applied with the rule
@@ -154,7 +160,9 @@ def mixed_arena(agents, num_games: int):
         idx = np.nonzero(live & (seat == az_seat))[0]
         for lo in range(0, len(idx), chunk):
             part = idx[lo:lo + chunk]
-            _, act, _, _ = eng.search(boards[part], (seat[part] + 1).astype(np.int8), params)
+            movers = (seat[part] + 1).astype(np.int8)
+            sides = np.full(len(part), 2 if az.current_player == 2 else 1, dtype=np.int8) if keep_agent_sides else movers
+            _, act, _, _ = eng.search(boards[part], movers, params, side_players=sides)
             action[part] = act
         live &= action >= 0                                  # no move available: the game counts as a draw
         idx = np.nonzero(live)[0]
@@ -175,8 +183,10 @@ def mixed_arena(agents, num_games: int):
     return winners
 
 
-def run_tournament(agents, num_games=100, results_dir=os.path.join("tournament", "results"), batched=None):
-    """run_tournament.py:12-42.  batched=None picks a batched engine arena when the pair allows it."""
+def run_tournament(agents, num_games=100, results_dir=os.path.join("tournament", "results"), batched=None,
+                   keep_agent_sides: bool = False):
+    """run_tournament.py:12-42.  batched=None picks a batched engine arena when the pair allows it.
+    keep_agent_sides: see play_match."""
     names = _names(agents)
     results = {n: 0 for n in names}
     results["draws"] = 0
@@ -184,15 +194,15 @@ def run_tournament(agents, num_games=100, results_dir=os.path.join("tournament",
         import torch
         batched = arena_capable(agents) or (mixed_arena_capable(agents) and torch.cuda.is_available())
     if batched and arena_capable(agents):
-        wa, wb, dr, _ = arena(agents, num_games)
+        wa, wb, dr, _ = arena(agents, num_games, keep_agent_sides=keep_agent_sides)
         results[names[0]], results[names[1]], results["draws"] = wa, wb, dr
     elif batched and mixed_arena_capable(agents):
-        for w in mixed_arena(agents, num_games):
+        for w in mixed_arena(agents, num_games, keep_agent_sides=keep_agent_sides):
             results["draws" if w is None else names[w]] += 1
     else:
         game = ConnectFourGame()
         for i in range(num_games):
-            results[play_match(agents, names, game, i % 2)] += 1
+            results[play_match(agents, names, game, i % 2, keep_agent_sides)] += 1
     os.makedirs(results_dir, exist_ok=True)
     path = os.path.join(results_dir, "tournament_results.json")
     with open(path, "w") as f:

@@ -121,6 +121,15 @@ typedef struct nnb_search_params {
     double  dirichlet_alpha;   /* AZ only; 0 disables root noise                   */
     double  dirichlet_eps;     /* AZ only; mixing weight of the noise              */
     uint64_t seed;       /* AZ noise / ROLLOUT playouts: counter-based RNG key     */
+    /* COMPAT, nnb_selfplay_round only: the colour whose stones fill the network's first input
+     * plane (agent.current_player, agent_code.py:85-87) while colour 1 / colour 2 is to move;
+     * 0 = the mover, which is what self_play keeps (train_alpha_zero.py:38,45).  {1, 1} is an
+     * agent whose current_player is never updated, as in run_tournament.py:21-22. */
+    int32_t side_of_colour[2];
+    /* nnb_selfplay_round only: give up with NNB_ERR_STATE once this many lock-step rounds (tree step +
+     * forward pass) have run and games are still unfinished; 0 = only the built-in bound, which no
+     * legal round reaches.  Unfinished games keep result = 2 in their records. */
+    int64_t round_limit;
 } nnb_search_params;
 
 /* One finished (or cut-off) self-play game.  Fixed size so records can be
@@ -239,13 +248,18 @@ int nnb_minimax(void *stream, int32_t n, const uint64_t *colour_boards, const in
  * action_out [n] = most visited child, lowest column on ties, -1 if the root got no
  * children (the reference returns None, agent_code.py:219-221).
  * root_value_out [n] (may be NULL) = the root's accumulated value sum.
+ * root_players [n] = the colour to move at each root (env.current_player, agent_code.py:167):
+ * the colour COMPAT places at every step of the descent.  side_players [n] (may be NULL =
+ * root_players) = the colour the leaf planes are encoded from (agent.current_player,
+ * agent_code.py:85-87), which the reference reads independently of the mover.  AZ mode always
+ * encodes a leaf from the side to move there and ignores side_players.
  * root_noise [n,7] (AZ mode, may be NULL): noise mixed into the root priors with weight
  * dirichlet_eps; when NULL and dirichlet_alpha > 0 the engine draws Dirichlet(alpha)
  * noise itself from its counter-based RNG (see nnb_dirichlet_noise).
  * stats_out (host pointer, may be NULL) is filled when the call returns.  Synchronous. */
 int nnb_search(nnb_engine *engine, void *stream, const nnb_search_params *params, int32_t n,
                const uint64_t *root_colour_boards, const int8_t *root_players,
-               const float *root_noise, int32_t *visits_out, int8_t *action_out,
+               const int8_t *side_players, const float *root_noise, int32_t *visits_out, int8_t *action_out,
                double *root_value_out, nnb_round_stats *stats_out);
 
 /* Plays n_games self-play games to the end, the same searcher on both sides (self_play,

@@ -139,12 +139,12 @@ typedef struct {
  * agent_code.py:144-234 with mcts.py:13-44.  Kept quirks (each is a line of the
  * reference): root.visits = 1 (:160); descent places the root mover's colour at
  * every depth (connect_four_game.py:50 then agent_code.py:176); the leaf is
- * encoded from the root mover's side (:85); absolute +-1 terminal reward
+ * encoded from agent.current_player's side (:85-87; `side`, the mover in self-play); absolute +-1 terminal reward
  * (:182-186) with no negation in the backup (mcts.py:40-44); priors discarded
  * (mcts.py:35-38); lowest column wins ties (mcts.py:30, agent_code.py:223).
  * Returns the selected column, or -1 when the root never got children.
  */
-static int compat_search_impl(u64 b1, u64 b2, int player, int sims, double c_puct, int eval_kind,
+static int compat_search_impl(u64 b1, u64 b2, int player, int side, int sims, double c_puct, int eval_kind,
                               orc_eval_fn fn, void *ctx, u64 seed, uint32_t game_id, uint32_t move_index,
                               int32_t *visits_out, orc_stats *st) {
     int cap = 1 + 7 * sims;
@@ -180,7 +180,8 @@ static int compat_search_impl(u64 b1, u64 b2, int player, int sims, double c_puc
             ++term;
         } else {
             int legal = orc_legal_mask(c1, c2);
-            u64 me = player == 1 ? c1 : c2, opp = player == 1 ? c2 : c1;
+            /* planes from agent.current_player (`side`), not from the mover (agent_code.py:85-87) */
+            u64 me = side == 1 ? c1 : c2, opp = side == 1 ? c2 : c1;
             if (eval_kind == ORC_EVAL_ROLLOUT) {
                 /* no counterpart in the reference: a uniformly random playout whose value is the
                    final position's get_reward() (absolute frame), the root mover moving first */
@@ -217,13 +218,19 @@ static int compat_search_impl(u64 b1, u64 b2, int player, int sims, double c_puc
 
 int orc_compat_search(u64 b1, u64 b2, int player, int sims, double c_puct, int eval_kind,
                       orc_eval_fn fn, void *ctx, int32_t *visits_out, orc_stats *st) {
-    return compat_search_impl(b1, b2, player, sims, c_puct, eval_kind, fn, ctx, 0, 0, 0, visits_out, st);
+    return compat_search_impl(b1, b2, player, player, sims, c_puct, eval_kind, fn, ctx, 0, 0, 0, visits_out, st);
+}
+
+/* the same search with the agent's side (agent.current_player) given apart from the mover */
+int orc_compat_search_sided(u64 b1, u64 b2, int player, int side, int sims, double c_puct, int eval_kind,
+                            orc_eval_fn fn, void *ctx, int32_t *visits_out, orc_stats *st) {
+    return compat_search_impl(b1, b2, player, side, sims, c_puct, eval_kind, fn, ctx, 0, 0, 0, visits_out, st);
 }
 
 /* same search with the rollout evaluator's RNG coordinates (seed, game, move index) */
 int orc_compat_search_seeded(u64 b1, u64 b2, int player, int sims, double c_puct, int eval_kind, u64 seed,
                              uint32_t game_id, uint32_t move_index, int32_t *visits_out, orc_stats *st) {
-    return compat_search_impl(b1, b2, player, sims, c_puct, eval_kind, NULL, NULL, seed, game_id, move_index,
+    return compat_search_impl(b1, b2, player, player, sims, c_puct, eval_kind, NULL, NULL, seed, game_id, move_index,
                               visits_out, st);
 }
 

@@ -62,6 +62,8 @@ def lib():
         L.orc_hash_value_f32.restype = C.c_double
         L.orc_compat_search.argtypes = [u64, u64, C.c_int, C.c_int, C.c_double, C.c_int, EVAL_FN,
                                         C.c_void_p, C.POINTER(C.c_int32), C.POINTER(Stats)]
+        L.orc_compat_search_sided.argtypes = [u64, u64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, EVAL_FN,
+                                              C.c_void_p, C.POINTER(C.c_int32), C.POINTER(Stats)]
         L.orc_selfplay_game.argtypes = [u64, u64, C.c_int, C.c_int, C.c_double, C.c_int, EVAL_FN,
                                         C.c_void_p, C.c_int, C.POINTER(C.c_int8),
                                         C.POINTER(C.c_int32), C.POINTER(C.c_int), C.POINTER(u64),
@@ -101,11 +103,13 @@ def drop(b1, b2, player, col):
     return bool(ok), x1.value, x2.value
 
 
-def compat_search(b1, b2, player, sims, c_puct, evaluator):
+def compat_search(b1, b2, player, sims, c_puct, evaluator, side=None):
+    """side: the colour the evaluator looks from (agent.current_player); None = the mover."""
     kind, fn, _keep = _eval_args(evaluator)
     visits = (C.c_int32 * 7)()
     st = Stats()
-    a = lib().orc_compat_search(b1, b2, player, sims, c_puct, kind, fn, None, visits, C.byref(st))
+    a = lib().orc_compat_search_sided(b1, b2, player, player if side is None else side, sims, c_puct, kind, fn,
+                                      None, visits, C.byref(st))
     return (None if a < 0 else a), list(visits), st
 
 

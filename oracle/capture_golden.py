@@ -124,11 +124,14 @@ def play_game(agent, max_plies=None):
     return moves, visits, game.get_result(), game.board.copy()
 
 
-def search_position(agent, board, player):
+def search_position(agent, board, player, side=None):
+    """One select_move from (board, player to move).  `side` is what agent.current_player holds
+    during the search (agent_code.py:85-87 reads it for the planes, independently of the mover
+    that agent_code.py:167 copies from the game); None = the mover, as self_play keeps it."""
     game = ConnectFourGame()
     game.board = board.copy()
     game.current_player = player
-    agent.current_player = player
+    agent.current_player = player if side is None else side
     a, probs = agent.select_move(game)
     total = agent.num_simulations - 1
     v = [int(round(float(p) * total)) for p in probs]
@@ -301,6 +304,67 @@ def capture_search():
     return {"games": games, "positions": positions}
 
 
+def capture_sided():
+    """Searches in which agent.current_player differs from the colour to move: the fixed
+    evaluators (bit-exact) and the seed-0 network (float dependent).  Also what the reference's
+    own tournament loop does, which never updates agent.current_player (run_tournament.py:21-22)."""
+    positions = []
+    pos = random_positions(16, seed=23, min_plies=1, max_plies=30)
+    for kind in ("hash_q8", "hash_f32"):
+        for sims in (60, 200):
+            agent = make_agent(kind, sims)
+            for (b, p) in pos:
+                for side in (1, 2):
+                    a, v = search_position(agent, b, p, side)
+                    positions.append({"evaluator": kind, "sims": sims, "c_puct": 1.4, "board": rp.board_to_str(b),
+                                      "player": p, "side": side, "action": a, "visits": v})
+        print(f"[sided] {kind} done", flush=True)
+    agent = make_agent(0, 60)
+    for (b, p) in pos[:12]:
+        side = 3 - p
+        a, v = search_position(agent, b, p, side)
+        positions.append({"evaluator": "net_seed0", "sims": 60, "c_puct": 1.4, "board": rp.board_to_str(b),
+                          "player": p, "side": side, "action": a, "visits": v})
+    print("[sided] net done", flush=True)
+    return {"positions": positions}
+
+
+def capture_timing():
+    """The CPU restatement (oracle/ref_port.py) timed next to the imported reference, same
+    container, same weights, same searches: how far the port's speed is from the reference's."""
+    # this container's 8 virtual CPUs are shared with other tenants: with 8 intra-op threads a batch-1
+    # forward pass takes 30x longer than with 2-4 (spinning workers lose their core), so both sides run
+    # with 4 threads; the ratio, not the absolute rate, is what this capture is for
+    torch.set_num_threads(4)
+    sd = rp.seeded_state_dict(0)
+    ev = rp.make_net_evaluator(sd)
+    out = {"cpu_count": os.cpu_count(), "torch_threads": torch.get_num_threads(), "legs": []}
+    for sims, plies in ((100, 8), (200, 6)):
+        agent = make_agent(0, sims)
+        game = ConnectFourGame()
+        game.reset()
+        agent.current_player = 1
+        board, player = rp.new_board(), 1
+        t_ref = t_port = 0.0
+        for _ in range(plies):
+            t0 = time.perf_counter()
+            a, _ = agent.select_move(game)
+            t_ref += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            a2, _ = rp.compat_search(board, player, sims, 1.4, ev)
+            t_port += time.perf_counter() - t0
+            assert a == a2, (a, a2)
+            game.make_move(a)
+            agent.current_player = game.current_player
+            _, player = rp.make_move(board, player, a)
+        out["legs"].append({"sims_per_move": sims, "plies": plies,
+                            "reference_sims_per_s": sims * plies / t_ref, "port_sims_per_s": sims * plies / t_port,
+                            "port_over_reference": t_ref / t_port})
+        print(f"[timing] S={sims}: reference {sims * plies / t_ref:.1f} sims/s, port {sims * plies / t_port:.1f} sims/s",
+              flush=True)
+    return out
+
+
 # ---------------------------------------------------------------- net vectors
 def state_dict_digest(sd):
     h = hashlib.sha256()
@@ -399,6 +463,14 @@ def main():
         with open(os.path.join(GOLDEN, "search.json"), "w") as f:
             json.dump(capture_search(), f, separators=(",", ":"))
         print("search.json written", flush=True)
+    if "sided" in which:
+        with open(os.path.join(GOLDEN, "search_sided.json"), "w") as f:
+            json.dump(capture_sided(), f, separators=(",", ":"))
+        print("search_sided.json written", flush=True)
+    if "timing" in which:
+        with open(os.path.join(GOLDEN, "port_vs_reference_timing.json"), "w") as f:
+            json.dump(capture_timing(), f, separators=(",", ":"))
+        print("port_vs_reference_timing.json written", flush=True)
     if "minimax" in which:
         with open(os.path.join(GOLDEN, "minimax.json"), "w") as f:
             json.dump(capture_minimax(), f, separators=(",", ":"))

@@ -275,8 +275,14 @@ def masked_priors(log_policy_row: np.ndarray, legal: list) -> np.ndarray:
 # Search (agent_code.py:144-234 + mcts.py:13-44), flat arrays instead of objects
 # --------------------------------------------------------------------------
 def compat_search(board: np.ndarray, player: int, num_simulations: int,
-                  c_puct: float, evaluator, stats: dict | None = None):
+                  c_puct: float, evaluator, stats: dict | None = None, side: int | None = None):
     """One reference search from (board, player to move).
+
+    `player` is env.current_player (agent_code.py:167), the colour placed during
+    descent; `side` is agent.current_player (agent_code.py:85-87), the colour the
+    leaf planes are encoded from.  The reference reads the two independently;
+    its self-play keeps them equal (train_alpha_zero.py:38,45), which is the
+    default here (side=None).
 
     Returns (selected_action, visits[7]) where visits are the root children's
     visit counts (0 for columns without a child).  Quirks kept on purpose:
@@ -284,13 +290,15 @@ def compat_search(board: np.ndarray, player: int, num_simulations: int,
       * descent places the ROOT mover's colour at every depth, because the
         player is flipped by make_move (connect_four_game.py:50) and flipped
         back at agent_code.py:176;
-      * the leaf is encoded from the root mover's perspective (agent_code.py:85);
+      * the leaf is encoded from the agent's side, `side`, at every depth (agent_code.py:85);
       * terminal reward is absolute (+1 colour 2 / -1 colour 1) and the backup
         does not negate it (mcts.py:40-44);
       * child priors are discarded (mcts.py:35-38);
       * ties go to the lowest column (strict '>' at mcts.py:30, first max at
         agent_code.py:223).
     """
+    if side is None:
+        side = player
     visits = [1]          # agent_code.py:160
     value = [0.0]
     parent = [-1]
@@ -329,7 +337,7 @@ def compat_search(board: np.ndarray, player: int, num_simulations: int,
             if not legal:                                # agent_code.py:190-193
                 reward = 0
             else:
-                reward = evaluator(b, player)            # agent_code.py:195-199,213
+                reward = evaluator(b, side)              # agent_code.py:195-199,213
                 net_calls += 1
                 first_child[node] = len(visits)          # mcts.py:35-38
                 n_child[node] = len(legal)

@@ -32,3 +32,9 @@ def search_golden():
 @pytest.fixture(scope="session")
 def net_golden_meta():
     return load_golden("net_seed0.json")
+
+
+@pytest.fixture(scope="session")
+def sided_golden():
+    """Searches captured from the reference with agent.current_player set apart from the mover."""
+    return load_golden("search_sided.json")

@@ -74,7 +74,7 @@ def test_argument_errors_are_reported(lib):
         assert b"out of range" in lib.nnb_last_error()
     assert lib.nnb_game_ops(None, -1, None, None, None, None, None, None) == -1
     assert lib.nnb_game_ops(None, 0, None, None, None, None, None, None) == 0      # empty input is fine
-    assert lib.nnb_search(None, None, None, 1, None, None, None, None, None, None, None) == -1
+    assert lib.nnb_search(None, None, None, 1, None, None, None, None, None, None, None, None) == -1
 
 
 def test_engine_fails_loudly_without_a_gpu():

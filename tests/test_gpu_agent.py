@@ -42,6 +42,29 @@ def test_select_move_replays_golden_games(torch_mod, search_golden):
             assert game.get_result() == g["result"]
 
 
+def test_select_move_reads_the_agents_own_side(torch_mod, sided_golden):
+    """select_move with agent.current_player different from game.current_player: the planes follow the
+    agent's attribute (agent_code.py:85-87), the stones placed during descent the game's mover
+    (agent_code.py:167,176) - vectors captured from the reference with the two set apart."""
+    from nnbattle.agents.alphazero.utils import initialize_agent
+    from nnbattle.game import ConnectFourGame
+    from oracle import ref_port as rp
+    cases = [c for c in sided_golden["positions"] if c["evaluator"] == "hash_f32" and c["sims"] == 60]
+    agent = initialize_agent(action_dim=7, state_dim=2, use_gpu=False, num_simulations=60, c_puct=1.4,
+                             load_model=False)
+    agent.evaluator = "hash_f32"
+    assert any(c["side"] != c["player"] for c in cases)
+    for c in cases:
+        game = ConnectFourGame()
+        game.board = rp.board_from_str(c["board"])
+        game.current_player = c["player"]
+        agent.current_player = c["side"]
+        action, probs = agent.select_move(game)
+        assert action == c["action"]
+        assert [int(round(float(p) * 59)) for p in probs] == c["visits"]
+        assert agent.current_player == c["side"] and game.current_player == c["player"]
+
+
 def test_select_move_on_finished_game_returns_none(torch_mod):
     from alphazero_amd.agent import initialize_agent
     from alphazero_amd.game import ConnectFourGame

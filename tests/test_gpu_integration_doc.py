@@ -29,13 +29,16 @@ def test_documented_ctypes_stub_runs_and_matches_the_engine():
     ns["load_weights"](handle, model)
     board = np.zeros((6, 7), dtype=np.int8)
     board[5][3] = 1
-    action, visits = ns["search"](handle, board, 2, 64, 1.4)
-    eng = Engine(max_games=1, max_sims=64)
+    action, visits = ns["search"](handle, board, 2, 2, 64, 1.4)
+    action_s, visits_s = ns["search"](handle, board, 2, 1, 64, 1.4)     # the agent still looks from colour 1
+    eng = Engine(max_games=1, max_sims=64, precision="f16")             # the stub's Config picks half inputs
     try:
         eng.load_state_dict(model.state_dict())
-        v, a, _, _ = eng.search(np.array([[1 << (3 * 7), 0]], dtype=np.uint64), np.array([2], dtype=np.int8),
-                                eng.params(64, 1.4))
+        root, mover = np.array([[1 << (3 * 7), 0]], dtype=np.uint64), np.array([2], dtype=np.int8)
+        v, a, _, _ = eng.search(root, mover, eng.params(64, 1.4))
+        vs, as_, _, _ = eng.search(root, mover, eng.params(64, 1.4), side_players=np.array([1], dtype=np.int8))
     finally:
         eng.close()
     assert action == int(a[0]) and visits == v[0].tolist() and sum(visits) == 63
+    assert action_s == int(as_[0]) and visits_s == vs[0].tolist() and sum(visits_s) == 63
     assert ns["lib"].nnb_engine_destroy(handle) == 0

@@ -189,6 +189,48 @@ def test_search_golden_positions(engine, oracle, search_golden, lockstep):
 
 
 @pytest.mark.parametrize("lockstep", [False, True])
+def test_search_golden_sided_positions(engine, oracle, sided_golden, lockstep):
+    """agent.current_player (side the leaf planes are encoded from) given apart from the colour to
+    move, as the reference reads them (agent_code.py:85-87 vs :167): vectors captured from the reference."""
+    co, rp = oracle
+    groups = {}
+    for case in sided_golden["positions"]:
+        if case["evaluator"] != "net_seed0":
+            groups.setdefault((case["evaluator"], case["sims"], case["c_puct"]), []).append(case)
+    for (ev, sims, c), cases in groups.items():
+        boards = np.array([rp.bitboards(rp.board_from_str(x["board"])) for x in cases], dtype=np.uint64)
+        players = np.array([x["player"] for x in cases], dtype=np.int8)
+        sides = np.array([x["side"] for x in cases], dtype=np.int8)
+        visits, action, _, _ = engine.search(boards, players, engine.params(sims, c, evaluator=ev, lockstep=lockstep),
+                                             side_players=sides)
+        assert visits.tolist() == [x["visits"] for x in cases], (ev, sims)
+        assert action.tolist() == [x["action"] for x in cases]
+
+
+def test_selfplay_side_of_colour_matches_sided_searches(engine, oracle):
+    """A round whose searches all look from colour 1 (an agent whose current_player is never updated,
+    run_tournament.py:21-22): every ply of every record equals the C oracle's sided search."""
+    from alphazero_amd.engine import trajectories_to_numpy
+    co, rp = oracle
+    pos = _random_positions(rp, co, 24, seed=314, max_plies=8)
+    boards = np.array([(p[0], p[1]) for p in pos], dtype=np.uint64)
+    players = np.array([p[2] for p in pos], dtype=np.int8)
+    for lockstep in (False, True):
+        traj, _ = engine.selfplay_round(len(pos), engine.params(48, 1.4, evaluator="hash_f32", lockstep=lockstep,
+                                                                side_of_colour=(1, 1)),
+                                        start_boards=boards, start_players=players)
+        swapped = 0
+        for r in trajectories_to_numpy(traj):
+            for k in range(int(r["length"])):
+                ply = r["plies"][k]
+                b1, b2, mover = int(ply["colour_boards"][0]), int(ply["colour_boards"][1]), int(ply["player"])
+                a, v, _ = co.compat_search(b1, b2, mover, 48, 1.4, "hash_f32", side=1)
+                assert ply["visits"].tolist() == v and int(ply["action"]) == a
+                swapped += int(mover == 2 and co.compat_search(b1, b2, mover, 48, 1.4, "hash_f32")[1] != v)
+        assert swapped > 10
+
+
+@pytest.mark.parametrize("lockstep", [False, True])
 def test_search_golden_games(engine, oracle, search_golden, lockstep):
     """Replays each golden self-play game ply by ply: the device search must pick the same
     move with the same root visit counts at every ply (S = 100..800, three evaluators)."""
@@ -345,3 +387,26 @@ def test_net_search_matches_cpu_reference_game(seed0_engine, oracle, net_golden_
     need = 0.75 if seed0_engine.precision == "f32" else 0.5
     assert agree >= int(need * len(boards)), (agree, len(boards))
     assert action.tolist()[:4] == g["moves"][:4]
+
+
+def test_net_search_sided_positions(seed0_engine, oracle, sided_golden):
+    """The network looking from agent.current_player while the other colour moves, against the
+    reference's own searches (seed-0 network, 60 simulations).  Float dependent like every real-network
+    search: the float32-faithful arithmetics are expected to reproduce every visit vector."""
+    co, rp = oracle
+    cases = [c for c in sided_golden["positions"] if c["evaluator"] == "net_seed0"]
+    boards = np.array([rp.bitboards(rp.board_from_str(x["board"])) for x in cases], dtype=np.uint64)
+    players = np.array([x["player"] for x in cases], dtype=np.int8)
+    sides = np.array([x["side"] for x in cases], dtype=np.int8)
+    assert (players != sides).all()
+    visits, action, _, _ = seed0_engine.search(boards, players, seed0_engine.params(60, 1.4, evaluator="net"),
+                                               side_players=sides)
+    same = sum(int(visits[i].tolist() == x["visits"]) for i, x in enumerate(cases))
+    plain, _, _, _ = seed0_engine.search(boards, players, seed0_engine.params(60, 1.4, evaluator="net"))
+    print(seed0_engine.precision, "sided net searches with identical visit vectors:", same, "of", len(cases))
+    assert (plain != visits).any()                         # the side is a real input
+    if seed0_engine.precision == "f16":
+        assert same >= len(cases) // 2
+    else:
+        assert same == len(cases)
+        assert action.tolist() == [x["action"] for x in cases]

@@ -115,6 +115,40 @@ def test_search_positions_py(search_golden):
         assert a == case["action"]
 
 
+def test_search_sided_positions(sided_golden):
+    """agent.current_player (the side the planes are encoded from, agent_code.py:85-87) given apart from
+    the colour to move (agent_code.py:167): both restatements against the reference's searches."""
+    fixed = [c for c in sided_golden["positions"] if c["evaluator"] != "net_seed0"]
+    assert len(fixed) == 128 and any(c["side"] != c["player"] for c in fixed)
+    differ = 0
+    for k, case in enumerate(fixed):
+        board = rp.board_from_str(case["board"])
+        b1, b2 = rp.bitboards(board)
+        a, v, _ = co.compat_search(b1, b2, case["player"], case["sims"], case["c_puct"], case["evaluator"],
+                                   side=case["side"])
+        assert v == case["visits"] and a == case["action"], case
+        if case["side"] != case["player"]:
+            _, v_same, _ = co.compat_search(b1, b2, case["player"], case["sims"], case["c_puct"], case["evaluator"])
+            differ += int(v_same != v)
+        if case["sims"] <= 60 and k % 4 == 0:
+            a, v = rp.compat_search(board, case["player"], case["sims"], case["c_puct"],
+                                    rp.EVALUATORS[case["evaluator"]], side=case["side"])
+            assert v == case["visits"] and a == case["action"]
+    assert differ > 20          # the side is a real input: swapping it changes the search
+
+
+def test_search_sided_net_positions_py(sided_golden, seed0_sd):
+    """The same with the seed-0 network as evaluator (float dependent: the CPU restatement runs the
+    same torch kernels as the capture did, so it is expected to agree exactly)."""
+    ev = rp.make_net_evaluator(seed0_sd)
+    cases = [c for c in sided_golden["positions"] if c["evaluator"] == "net_seed0"]
+    assert len(cases) == 12
+    for case in cases[:6]:
+        a, v = rp.compat_search(rp.board_from_str(case["board"]), case["player"], case["sims"], case["c_puct"], ev,
+                                side=case["side"])
+        assert v == case["visits"] and a == case["action"]
+
+
 def test_search_games_c(search_golden):
     assert len(search_golden["games"]) == 12
     for g in search_golden["games"]:
