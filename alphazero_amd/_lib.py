@@ -64,6 +64,7 @@ SIGNATURES = {
     "nnb_net_forward_planes": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P, _P, _P]),
     "nnb_search": (C.c_int, [_P, _P, C.POINTER(SearchParams), C.c_int32, _P, _P, _P, _P, _P, _P, _P,
                              C.POINTER(RoundStats)]),
+    "nnb_search_static": (C.c_int, [_P, C.POINTER(SearchParams), C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "nnb_dirichlet_noise": (C.c_int, [_P, C.c_int32, C.c_uint64, _P, _P, _P, C.c_double, _P]),
     "nnb_selfplay_round": (C.c_int, [_P, _P, C.POINTER(SearchParams), C.c_int32, C.c_int32, _P, _P,
                                      _P, C.POINTER(RoundStats)]),

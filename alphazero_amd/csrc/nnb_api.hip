@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -409,6 +410,66 @@ int collect_stats(nnb_engine *e, hipStream_t st, nnb_round_stats *out, long long
     return NNB_OK;
 }
 
+// ---- search state of nnb_search_static: one fixed array per GPU, no allocation ----------------
+constexpr int kStaticRoots = NNB_STATIC_MAX_ROOTS, kStaticSims = NNB_STATIC_MAX_SIMS;
+constexpr size_t kStaticPool = 8;                   // root + its children: all the fused kernel hands to the readout
+constexpr size_t kStaticBytes = 512 * 1024;
+constexpr int kMaxDevices = 64;
+
+}  // namespace
+
+// Every GPU the library runs on holds its own copy of this array at its own address until the process
+// ends.  In host code the name is only a handle for hipGetSymbolAddress; kernels get the address it returns.
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+namespace {
+
+struct LogChunk { double v[256]; };                 // a piece of the log table passed as a kernel argument
+__global__ void store_log_chunk_kernel(double *dst, LogChunk c, int n) {
+    const int i = threadIdx.x;
+    if (i < n) dst[i] = c.v[i];
+}
+
+struct StaticState {
+    bool ready = false;
+    void *ptr = nullptr;                            // device address of `scratch` on this GPU
+    EngineDev dev;
+    size_t fused_lds_prepared = 0;
+};
+StaticState g_static[kMaxDevices];
+std::mutex g_static_mutex;
+
+// First call on a device: resolve the array's address there, lay the search state out in it, clear it and
+// fill the log table (values from the host's libm, handed over as kernel arguments: no copy, no allocation).
+int static_state(hipStream_t st, StaticState **out) {
+    int device = -1;
+    HIP_TRY(hipGetDevice(&device));
+    if (device < 0 || device >= kMaxDevices) return fail(NNB_ERR_ARG, "device ordinal %d out of range", device);
+    StaticState &s = g_static[device];
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    if (!s.ready) {
+        void *ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr || reinterpret_cast<uintptr_t>(ptr) % kAlign) return fail(NNB_ERR_HIP, "bad address for the static search state");
+        Carver c(ptr);
+        carve_state(kStaticRoots, kStaticPool, kStaticSims, 0, c, s.dev);
+        if (c.off > kStaticBytes) return fail(NNB_ERR_WORKSPACE, "static search state needs %zu bytes, array has %zu", c.off, kStaticBytes);
+        HIP_TRY(hipMemsetAsync(ptr, 0, kStaticBytes, st));
+        const int n_log = kStaticSims + 8;
+        for (int base = 0; base < n_log; base += 256) {
+            LogChunk chunk;
+            const int n = n_log - base < 256 ? n_log - base : 256;
+            for (int i = 0; i < 256; ++i) chunk.v[i] = std::log((double)(base + i + 1));
+            store_log_chunk_kernel<<<1, 256, 0, st>>>(s.dev.log_table + base, chunk, n);
+        }
+        HIP_TRY(hipGetLastError());
+        s.ptr = ptr;
+        s.ready = true;
+    }
+    *out = &s;
+    return NNB_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -690,6 +751,61 @@ int nnb_dirichlet_noise(void *stream, int32_t n, uint64_t seed, const int32_t *g
     if (!(alpha > 0.0) || !std::isfinite(alpha)) return fail(NNB_ERR_ARG, "alpha must be finite and > 0");
     launch_dirichlet_noise(static_cast<hipStream_t>(stream), n, seed, game_ids, move_indices, legal_masks, alpha,
                            noise_out);
+    HIP_TRY(hipGetLastError());
+    return NNB_OK;
+}
+
+int nnb_search_static(void *stream, const nnb_search_params *p, int32_t n, const uint64_t *root_colour_boards,
+                      const int8_t *root_players, const int8_t *side_players, const float *root_noise,
+                      int32_t *visits_out, int8_t *action_out, double *root_value_out) {
+    if (!p) return fail(NNB_ERR_ARG, "params is null");
+    if (n < 0 || n > kStaticRoots) return fail(NNB_ERR_ARG, "n = %d out of range [0, NNB_STATIC_MAX_ROOTS = %d]", n, kStaticRoots);
+    if (p->sims < 1 || p->sims > kStaticSims)
+        return fail(NNB_ERR_ARG, "sims = %d out of range [1, NNB_STATIC_MAX_SIMS = %d]", p->sims, kStaticSims);
+    if (p->mode != NNB_MODE_COMPAT && p->mode != NNB_MODE_AZ) return fail(NNB_ERR_ARG, "unknown mode %d", p->mode);
+    if (p->evaluator <= NNB_EVAL_NET || p->evaluator > NNB_EVAL_ROLLOUT)
+        return fail(NNB_ERR_ARG, "nnb_search_static runs the fixed evaluators only (CONST, HASH_Q8, HASH_F32, ROLLOUT), not %d",
+                    p->evaluator);
+    if (p->flags != 0) return fail(NNB_ERR_ARG, "nnb_search_static takes no flags (the fused tree kernel only)");
+    if (!(p->c_puct >= 0.0) || !std::isfinite(p->c_puct)) return fail(NNB_ERR_ARG, "c_puct must be finite and >= 0");
+    if (p->weight_set < 0 || p->weight_set >= 8 || p->weight_set_colour2_plus1 < 0 || p->weight_set_colour2_plus1 > 8)
+        return fail(NNB_ERR_ARG, "weight set out of range [0, 8)");
+    for (int k = 0; k < 2; ++k)
+        if (p->side_of_colour[k] < 0 || p->side_of_colour[k] > 2)
+            return fail(NNB_ERR_ARG, "side_of_colour[%d] = %d is not 0 (the mover), 1 or 2", k, p->side_of_colour[k]);
+    const bool az = p->mode == NNB_MODE_AZ;
+    if (az) {
+        if (!(p->dirichlet_eps >= 0.0 && p->dirichlet_eps <= 1.0)) return fail(NNB_ERR_ARG, "dirichlet_eps must be in [0, 1]");
+        if (!(p->dirichlet_alpha >= 0.0) || !std::isfinite(p->dirichlet_alpha))
+            return fail(NNB_ERR_ARG, "dirichlet_alpha must be finite and >= 0");
+    }
+    if (n == 0) return NNB_OK;
+    if (!root_colour_boards || !root_players) return fail(NNB_ERR_ARG, "root boards / players is null");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    StaticState *s = nullptr;
+    int rc = static_state(st, &s);
+    if (rc) return rc;
+    SearchDev sd = to_dev(*p);
+    if (!az) { sd.dirichlet_eps = 0.0; sd.dirichlet_alpha = 0.0; }
+    int make_noise = 0;
+    if (az && sd.dirichlet_eps > 0.0 && !root_noise) {
+        if (!(sd.dirichlet_alpha > 0.0)) return fail(NNB_ERR_ARG, "dirichlet_eps > 0 needs dirichlet_alpha > 0 or root_noise");
+        make_noise = 1;
+    }
+    const size_t pool_nodes = 1 + 7 * (size_t)p->sims;
+    const size_t lds = pool_nodes * sizeof(Node) + (az ? pool_nodes * sizeof(float) : (size_t)(p->sims + 2) * sizeof(double));
+    if (lds > kFusedLdsLimit) return fail(NNB_ERR_ARG, "sims = %d needs %zu bytes of LDS (limit %zu)", p->sims, lds, kFusedLdsLimit);
+    if (lds > s->fused_lds_prepared) {
+        HIP_TRY(prepare_tree_fused(lds));
+        s->fused_lds_prepared = lds;
+    }
+    EngineDev d = s->dev;                   // every pointer in it derives from the address hipGetSymbolAddress returned
+    d.n_games = n;
+    launch_search_init(st, d, reinterpret_cast<const u64 *>(root_colour_boards), root_players, side_players,
+                       p->rng_game_base, root_noise);
+    launch_tree_init(st, d, sd, make_noise, 0);
+    launch_tree_fused(st, d, sd, lds);
+    launch_readout(st, d, sd, visits_out, action_out, root_value_out, nullptr);
     HIP_TRY(hipGetLastError());
     return NNB_OK;
 }

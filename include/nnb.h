@@ -262,6 +262,24 @@ int nnb_search(nnb_engine *engine, void *stream, const nnb_search_params *params
                const int8_t *side_players, const float *root_noise, int32_t *visits_out, int8_t *action_out,
                double *root_value_out, nnb_round_stats *stats_out);
 
+/* nnb_search for callers that cannot allocate device memory - code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  The
+ * search state that nnb_search keeps in the engine's workspace lives in a fixed array inside the
+ * library instead (512 KB, one copy per GPU, held until the process ends), so there is no engine, no
+ * workspace and no call to hipMalloc / hipFree or to any allocating routine; the first call on a
+ * device lays that array out and fills its log table.  Limits: n <= NNB_STATIC_MAX_ROOTS roots,
+ * params->sims <= NNB_STATIC_MAX_SIMS, a fixed evaluator (CONST, HASH_Q8, HASH_F32 or ROLLOUT - the
+ * network's activations do not fit), params->flags == 0; anything beyond is refused with NNB_ERR_ARG.
+ * Arguments and results are those of nnb_search, bit for bit; there are no statistics, and the call is
+ * ASYNCHRONOUS on `stream` on the current device.  All calls on one GPU share that GPU's array: calls
+ * that overlap in time on one GPU (two streams, two threads) race and must be serialised by the caller. */
+#define NNB_STATIC_MAX_ROOTS 256
+#define NNB_STATIC_MAX_SIMS 800
+int nnb_search_static(void *stream, const nnb_search_params *params, int32_t n,
+                      const uint64_t *root_colour_boards, const int8_t *root_players,
+                      const int8_t *side_players, const float *root_noise, int32_t *visits_out,
+                      int8_t *action_out, double *root_value_out);
+
 /* Plays n_games self-play games to the end, the same searcher on both sides (self_play,
  * train_alpha_zero.py:33-55), or one weight set per colour (run_tournament.py:12-42).
  * At most max_games games are in flight, all advancing in lock step; when n_games is
