@@ -16,8 +16,8 @@ EVAL_NET, EVAL_CONST, EVAL_HASH_Q8, EVAL_HASH_F32, EVAL_ROLLOUT = 0, 1, 2, 3, 4
 EVALUATORS = {"net": EVAL_NET, "const": EVAL_CONST, "hash_q8": EVAL_HASH_Q8,
               "hash_f32": EVAL_HASH_F32, "rollout": EVAL_ROLLOUT}
 FLAG_LOCKSTEP = 1
-NET_F16, NET_F32 = 0, 1
-PRECISIONS = {"f16": NET_F16, "f32": NET_F32}
+NET_F16, NET_F32, NET_F32S = 0, 1, 2
+PRECISIONS = {"f16": NET_F16, "f32": NET_F32, "f32s": NET_F32S}
 MODES = {"compat": MODE_COMPAT, "az": MODE_AZ}
 
 
@@ -62,6 +62,7 @@ SIGNATURES = {
     "nnb_ucb_scores": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_double, _P]),
     "nnb_net_forward": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P, _P, _P, _P, _P]),
     "nnb_net_forward_planes": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P, _P, _P]),
+    "nnb_debug_activations": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int32, _P]),
     "nnb_search": (C.c_int, [_P, _P, C.POINTER(SearchParams), C.c_int32, _P, _P, _P, _P, _P, _P, _P,
                              C.POINTER(RoundStats)]),
     "nnb_search_static": (C.c_int, [_P, C.POINTER(SearchParams), C.c_int32, _P, _P, _P, _P, _P, _P, _P]),

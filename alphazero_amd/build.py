@@ -15,6 +15,7 @@ SOURCES = [
     ("tree_kernels.hip", ["-ffp-contract=off"]),
     ("net_kernels.hip", []),
     ("net_kernels_f16.hip", []),
+    ("net_kernels_split.hip", []),
     ("nnb_api.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -39,6 +39,16 @@ void launch_dirichlet_noise(hipStream_t st, int n, u64 seed, const int32_t *game
 void launch_stats_reduce(hipStream_t st, const EngineDev &e);
 void launch_fixed_eval(hipStream_t st, const EngineDev &e, const SearchDev &p, int batch, int parity);
 
+// Power-of-two scales of the split-operand path (net_kernels_split.hip), in device memory, written
+// when the weights are loaded: s* puts the tensor's largest magnitude just under 2^14, inv_s* = 1/s*.
+struct SplitScales {
+    float sw0, inv_sw0;        // 2->128 layer weights
+    float sa1, inv_sa1;        // that layer's output (static: bounded by its weights, the inputs being 0/1)
+    float sw2, inv_sw2;        // first 128->128 layer weights
+    float sw4, inv_sw4;        // second 128->128 layer weights
+    float swf, inv_swf;        // linear layer weights
+};
+
 // net_kernels.hip
 struct NetWeights {            // one resident weight set, kernel layouts
     float *conv0_w, *conv0_b;  // [128][2][4][4], [128]
@@ -49,6 +59,11 @@ struct NetWeights {            // one resident weight set, kernel layouts
     // half-precision-input path (net_kernels_f16.hip); null when the engine runs the f32 path
     void *conv2_wh, *conv4_wh; // half [16][8][2][128][8]
     void *fc_wh;               // half [720][2][1024][8]
+    // split-operand path: the arrays above hold the hi halves of the scaled weights, these the lo halves
+    void *conv2_wl, *conv4_wl, *fc_wl;
+    void *conv0_wh, *conv0_wl; // half [128][32]
+    SplitScales *sp_scales;
+    void *sp_maxbits;          // 4 x uint32 scratch of the weight preparation
 };
 struct NetBuffers {            // activations, channels-last float32
     float *act1;               // [G][7][8][128]
@@ -58,6 +73,8 @@ struct NetBuffers {            // activations, channels-last float32
     float *fcpart;             // [2][G][1024] split-K partial sums (f16 path)
     float *fc_b1, *fcpart_b1;  // the same two for the second leaf batch of a two-network arena
     float *act1_b1, *act2_b1, *act3_b1;   // and its convolution buffers (the two batches run on two streams)
+    float *act2_inv, *act3_inv;           // split-operand path: 1 / scale of each board's activations, [G] each
+    float *act2_inv_b1, *act3_inv_b1;
     int max_rows;              // G
 };
 enum NetStage { NET_CONV0 = 0, NET_CONV2 = 1, NET_CONV4 = 2, NET_FC = 3, NET_HEADS = 4 };
@@ -83,5 +100,15 @@ void launch_repack_f16(hipStream_t st, const NetWeights &dst, const float *conv2
 void launch_net_stage_f16(hipStream_t st, int stage, const NetWeights &w, const NetBuffers &b, const u64 *side,
                           const uint8_t *legal, float *logp_out, float *value_out, float *prior_out,
                           const int32_t *count_ptr, int n_max);
+
+// net_kernels_split.hip: same stages with every float32 operand carried as a hi + lo pair of halves
+// (three MFMAs per product, float32-faithful)
+hipError_t prepare_net_kernels_split();
+void launch_repack_split(hipStream_t st, const NetWeights &dst, const float *conv0_w, const float *conv0_b,
+                         const float *conv2_w, const float *conv4_w, const float *fc_w);
+void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, const NetBuffers &b, const u64 *side,
+                            const uint8_t *legal, float *logp_out, float *value_out, float *prior_out,
+                            const int32_t *count_ptr, int n_max);
+void launch_split_to_f32(hipStream_t st, const void *act, const float *inv_scale, int cells, int n, float *out);
 
 }  // namespace nnb

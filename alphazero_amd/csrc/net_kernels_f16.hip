@@ -12,21 +12,14 @@
 #include "engine_layout.h"
 #include "kernels.h"
 #include "heads_math.h"
+#include "mfma_tiles.h"
 
 namespace nnb {
 
 using c4::u64;
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int batch_count16(const int32_t *count_ptr, int n_fixed) {
     return count_ptr ? *count_ptr : n_fixed;
-}
-
-__device__ __forceinline__ half8 as_half8(uint4 v) {
-    union { uint4 u; half8 h; } x;
-    x.u = v;
-    return x.h;
 }
 
 // ---------------------------------------------------------------------------
@@ -77,12 +70,6 @@ __device__ unsigned long long g_dbg_clk[2];
 #endif
 constexpr int CONV_RS = 17;                      // LDS stride of one position in 16-byte chunks
 
-// MFMA row (lane & 31) -> output cell within the tile.  ds_read_b128 services lanes
-// {0-3,12-15,20-27} and {4-11,16-19,28-31} (and the same +32) as two groups of 16; sigma
-// gives the first group cells 0..15 and the second cells 16..31.
-__host__ __device__ constexpr int sigma(int m) {
-    return m < 4 ? m : m < 12 ? m + 12 : m < 16 ? m - 8 : m < 20 ? m + 8 : m < 28 ? m - 12 : m;
-}
 
 // ABLATE (timing experiments only, 0 in the product): 1 skip staging, 2 reuse one A fragment,
 // 4 reuse one weight fragment, 8 skip the output stores.
@@ -321,13 +308,6 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv_mid_f16_kernel(const
 // input pixel is zero.  Block = 256*MH threads: wave w owns output channels 32*(w&3)..+31 and
 // cells 32*(w>>2)..+31 of every row.
 // ---------------------------------------------------------------------------
-__host__ __device__ constexpr int conv_board_stride(int ih, int iw) {
-    int s = ih * (iw + 2);
-    while ((s & 15) != ((iw + 1) & 15)) ++s;
-    return s;
-}
-__host__ __device__ constexpr int rows_t0(int kh) { return kh < 2 ? 2 - kh : 0; }
-__host__ __device__ constexpr int rows_t1(int ih, int kh) { return (ih + 2 - kh) < (ih + 1) ? (ih + 2 - kh) : (ih + 1); }
 
 template <int IH, int IW, int ARING, int BRING, int KH, bool LAST>
 __device__ __forceinline__ void conv_rows_body(f32x16 (&acc)[IH + 1], uint4 (&afrag)[ARING], uint4 (&bring)[BRING],

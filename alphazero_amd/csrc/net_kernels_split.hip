@@ -1,0 +1,654 @@
+// Float32-faithful variant of the policy-value network kernels (gfx950) on the half-input matrix cores.
+//
+// Connect4Net.forward (nnbattle/agents/alphazero/network.py:43-50) multiplies in float32.  The exact
+// f32 MFMA (v_mfma_f32_32x32x2_f32, net_kernels.hip) runs at 1/16 of the half-input rate.  Here every
+// float32 operand x is carried as a PAIR of halves, x*s = hi + lo with hi = half(x*s) and
+// lo = half(x*s - hi), s a power of two that puts the largest magnitude of the tensor just under 2^14
+// (so hi never overflows and lo stays a normal half for everything within 2^-17 of the maximum).
+// hi + lo reproduces x*s to 2^-22 relative (float32 keeps 2^-24), and a product becomes three MFMAs
+//     a*w*(sa*sw) ~= ah*wh + ah*wl + al*wh          (al*wl, 2^-22 of the product, is dropped)
+// on v_mfma_f32_32x32x16_f16 with float32 accumulation; the epilogue multiplies by 1/(sa*sw), exactly.
+// Weights get one scale per layer at load time.  Activations get one scale PER BOARD, taken from that
+// board's own maximum by the kernel that produces them, so a position's outputs do not depend on what
+// else is in the batch.  Bias, ReLU, the heads, log-softmax and tanh are float32 as in the other paths.
+//
+// Activation layout in memory: [board][cell][256 halves] = the 128 hi halves of the cell's channels,
+// then the 128 lo halves (512 bytes per cell), plus one float per board: 1/s.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "c4_bits.h"
+#include "engine_layout.h"
+#include "kernels.h"
+#include "heads_math.h"
+#include "mfma_tiles.h"
+
+namespace nnb {
+
+using c4::u64;
+
+constexpr int SP_RS = 33;                 // 16-byte chunks per LDS position: 16 hi, 16 lo, one pad (33 == 1 mod 16)
+constexpr int SP_PB = SP_RS * 16;         // bytes per position
+constexpr int SP_LO = 256;                // byte offset of the lo halves inside a position
+
+__device__ __forceinline__ int batch_count_sp(const int32_t *count_ptr, int n_fixed) {
+    return count_ptr ? *count_ptr : n_fixed;
+}
+
+// Power of two s with m*s in [2^13, 2^14) for a finite m >= 2^-113, else 1; inv = 1/s.
+__device__ __forceinline__ float pow2_scale(float m, float &inv) {
+    const unsigned e = (__float_as_uint(m) >> 23) & 0xFFu;
+    if (e < 14u || e == 255u) { inv = 1.0f; return 1.0f; }
+    inv = __uint_as_float((e - 13u) << 23);
+    return __uint_as_float((267u - e) << 23);
+}
+
+__device__ __forceinline__ void split_half(float x, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);       // exact difference, then rounded to half
+}
+
+// ---------------------------------------------------------------------------
+// Weight preparation (once per nnb_load_weights)
+// ---------------------------------------------------------------------------
+// max |w| over a tensor, as float bits (order-preserving for non-negative floats)
+__global__ void absmax_kernel(const float *__restrict__ w, size_t n, unsigned *__restrict__ out) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// One thread: the layer scales from the maxima, and the static scale of the 2->128 layer's output.
+// Its inputs are 0/1 planes, so an output of channel n is at most bias[n] + the sum of n's positive weights.
+__global__ void split_scales_kernel(const unsigned *__restrict__ maxbits, const float *__restrict__ w0,
+                                    const float *__restrict__ b0, SplitScales *__restrict__ sc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float inv;
+    sc->sw0 = pow2_scale(__uint_as_float(maxbits[0]), inv); sc->inv_sw0 = inv;
+    sc->sw2 = pow2_scale(__uint_as_float(maxbits[1]), inv); sc->inv_sw2 = inv;
+    sc->sw4 = pow2_scale(__uint_as_float(maxbits[2]), inv); sc->inv_sw4 = inv;
+    sc->swf = pow2_scale(__uint_as_float(maxbits[3]), inv); sc->inv_swf = inv;
+    float bound = 0.f;
+    for (int n = 0; n < 128; ++n) {
+        float s = b0[n];
+        for (int k = 0; k < 32; ++k) s += fmaxf(w0[n * 32 + k], 0.f);
+        bound = fmaxf(bound, s);
+    }
+    sc->sa1 = pow2_scale(bound, inv); sc->inv_sa1 = inv;
+}
+
+// Conv2d weight f32 [n=128][c=128][kh][kw] -> hi / lo halves [tap][ks=c/16][h=(c%16)/8][n][c%8]
+__global__ void repack_conv_split_kernel(const float *__restrict__ w, const float *__restrict__ scale,
+                                         _Float16 *__restrict__ wh, _Float16 *__restrict__ wl) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 128 * 128 * 16) return;
+    int j = i & 7, n = (i >> 3) & 127, h = (i >> 10) & 1, ks = (i >> 11) & 7, tap = i >> 14;
+    int c = ks * 16 + h * 8 + j, kh = tap >> 2, kw = tap & 3;
+    split_half(w[((n * 128 + c) * 4 + kh) * 4 + kw] * *scale, wh[i], wl[i]);
+}
+
+// Linear weight f32 [n=1024][c*90 + hw] -> hi / lo halves [ks=kk/16][h][n][kk%8], kk = hw*128 + c
+__global__ void repack_fc_split_kernel(const float *__restrict__ w, const float *__restrict__ scale,
+                                       _Float16 *__restrict__ wh, _Float16 *__restrict__ wl) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)1024 * 11520) return;
+    int j = i & 7, n = (i >> 3) & 1023, h = (i >> 13) & 1;
+    int ks = (int)(i >> 14);
+    int kk = ks * 16 + h * 8 + j, hw = kk >> 7, c = kk & 127;
+    split_half(w[(size_t)n * 11520 + c * 90 + hw] * *scale, wh[i], wl[i]);
+}
+
+// 2->128 layer: [n][k = plane*16 + kh*4 + kw] keeps its order
+__global__ void repack_conv0_split_kernel(const float *__restrict__ w, const float *__restrict__ scale,
+                                          _Float16 *__restrict__ wh, _Float16 *__restrict__ wl) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 128 * 32) return;
+    split_half(w[i] * *scale, wh[i], wl[i]);
+}
+
+// ---------------------------------------------------------------------------
+// conv 128->128, 4x4, pad 2, + bias + ReLU (network.py:31-34), row-tile implicit GEMM with split
+// operands.  Same tiling as conv_rows_f16_kernel: an MFMA tile is ONE OUTPUT ROW of the block's NB
+// boards (cells board-major, NB*OW <= 32), so the (output row, kernel row) pairs that read only
+// padding are known at compile time and skipped; wave w owns output channels 32w..32w+31 for all
+// output rows.  The LDS image holds, per input pixel, one position of 528 bytes (hi halves, lo halves,
+// pad) with zero positions around every image row; a lane's fragment addresses are one base plus
+// compile-time offsets, the lo fragment 256 bytes behind the hi one.  One block per CU (the image of
+// three boards takes 145 KB), one wave per SIMD: fragments come through a register ring filled
+// ARING steps ahead, weights stream L2 -> registers BRING-1 k-steps ahead.
+//
+// FUSE_IN (first 128->128 layer): the input image is not read from memory but computed in place -
+// leaf encode (AlphaZeroAgent.preprocess, agent_code.py:76-89) and the 2->128 convolution
+// (network.py:29-30) from the side boards, with the layer's static output scale.
+// ---------------------------------------------------------------------------
+template <int IH, int IW, int ARING, int BRING, int KH, bool LAST>
+__device__ __forceinline__ void conv_split_body(f32x16 (&acc)[IH + 1], u32x4 (&ahi)[ARING], u32x4 (&alo)[ARING],
+                                                u32x4 (&bh)[BRING], u32x4 (&bl)[BRING], const unsigned char *smem,
+                                                int lane_base, int kw, const u32x4 *__restrict__ wlh,
+                                                const u32x4 *__restrict__ wll) {
+    constexpr int W2 = IW + 2, PB = SP_PB;
+    constexpr int T0 = rows_t0(KH), NT = rows_t1(IH, KH) - T0, STEPS = 8 * NT;
+    constexpr int KHN = LAST ? KH + 1 : KH;                      // kernel row of the body that runs next
+    constexpr bool HAS_NEXT = !(LAST && KH == 3);
+    constexpr int T0N = rows_t0(KHN & 3), NTN = rows_t1(IH, KHN & 3) - T0N;
+    static_assert(STEPS % ARING == 0, "ring depth must divide the fragment pairs per tap");
+    const int vb = lane_base + ((KH - 2) * W2 + kw - 2) * PB;
+    const int vbn = LAST ? lane_base + ((KHN - 2) * W2 - 2) * PB : vb + PB;
+    const int step0 = (KH * 4 + kw) * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        {                                                        // weights BRING-1 k-steps ahead
+            int nxt = step0 + ks + BRING - 1;
+            nxt = nxt < 128 ? nxt : 127;
+            bh[(ks + BRING - 1) & (BRING - 1)] = wlh[nxt * 256];
+            bl[(ks + BRING - 1) & (BRING - 1)] = wll[nxt * 256];
+        }
+        const half8 wh = as_half8(bh[ks & (BRING - 1)]), wl = as_half8(bl[ks & (BRING - 1)]);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int f = ks * NT + i, g = f + ARING;
+            const half8 xh = as_half8(ahi[f % ARING]), xl = as_half8(alo[f % ARING]);
+            acc[T0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, acc[T0 + i], 0, 0, 0);
+            acc[T0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, acc[T0 + i], 0, 0, 0);
+            acc[T0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, acc[T0 + i], 0, 0, 0);
+            if (g < STEPS) {
+                const unsigned char *p = smem + vb + (T0 + g % NT) * (W2 * PB) + (g / NT) * 32;
+                ahi[g % ARING] = *reinterpret_cast<const u32x4 *>(p);
+                alo[g % ARING] = *reinterpret_cast<const u32x4 *>(p + SP_LO);
+            } else if (HAS_NEXT) {
+                const int gg = g - STEPS;
+                const unsigned char *p = smem + vbn + (T0N + gg % NTN) * (W2 * PB) + (gg / NTN) * 32;
+                ahi[g % ARING] = *reinterpret_cast<const u32x4 *>(p);
+                alo[g % ARING] = *reinterpret_cast<const u32x4 *>(p + SP_LO);
+            }
+            __builtin_amdgcn_sched_barrier(0);                   // keep the MFMA / LDS-read interleave as written
+        }
+    }
+}
+
+// Epilogue pieces for lane half H (compile time, so every cell index below is a constant expression).
+// Step 1: v = ReLU(acc * k[board] + bias) in place, and this lane's maximum per board.
+template <int IH, int IW, int NB, int H>
+__device__ __forceinline__ void conv_split_finish(f32x16 (&acc)[IH + 1], const float (&kin)[NB], float bv,
+                                                  float (&bmax)[NB]) {
+    constexpr int OH = IH + 1, OW = IW + 1, RC = NB * OW;
+    static_for<OH>([&](auto T) __attribute__((always_inline)) {
+        static_for<16>([&](auto Rr) __attribute__((always_inline)) {
+            constexpr int t = decltype(T)::value, r = decltype(Rr)::value;
+            constexpr int c = sigma((r & 3) + 8 * (r >> 2) + 4 * H);
+            if constexpr (c < RC) {
+                const float v = fmaxf(__builtin_fmaf(acc[t][r], kin[c / OW], bv), 0.f);
+                acc[t][r] = v;
+                bmax[c / OW] = fmaxf(bmax[c / OW], v);
+            }
+        });
+    });
+}
+
+// Step 2: quantise with the board's scale and put hi / lo into the output tile in LDS.
+template <int IH, int IW, int NB, int H>
+__device__ __forceinline__ void conv_split_store(const f32x16 (&acc)[IH + 1], const float (&sout)[NB],
+                                                 _Float16 *ldsh, int ch) {
+    constexpr int OH = IH + 1, OW = IW + 1, OP = OH * OW, RC = NB * OW;
+    static_for<OH>([&](auto T) __attribute__((always_inline)) {
+        static_for<16>([&](auto Rr) __attribute__((always_inline)) {
+            constexpr int t = decltype(T)::value, r = decltype(Rr)::value;
+            constexpr int c = sigma((r & 3) + 8 * (r >> 2) + 4 * H);
+            if constexpr (c < RC) {
+                constexpr int R = (c / OW) * OP + t * OW + c % OW;
+                _Float16 hi, lo;
+                split_half(acc[t][r] * sout[c / OW], hi, lo);
+                ldsh[R * (SP_PB / 2) + ch] = hi;
+                ldsh[R * (SP_PB / 2) + 128 + ch] = lo;
+            }
+        });
+    });
+}
+
+constexpr size_t conv_split_lds_bytes(int ih, int iw, int nb) {
+    int npos = 2 + nb * conv_board_stride(ih, iw) + 2, m = nb * (ih + 1) * (iw + 1);
+    return (size_t)(npos > m ? npos : m) * SP_PB + 256;         // + the per-wave board maxima
+}
+
+template <int IH, int IW, int NB, int BRING, int ARING, bool FUSE_IN>
+__global__ __launch_bounds__(256, 1) void conv_rows_split_kernel(const u32x4 *__restrict__ in,
+                                                                 const float *__restrict__ in_inv_scale,
+                                                                 const u32x4 *__restrict__ wph,
+                                                                 const u32x4 *__restrict__ wpl,
+                                                                 const float *__restrict__ bias,
+                                                                 const SplitScales *__restrict__ sc,
+                                                                 u32x4 *__restrict__ out,
+                                                                 float *__restrict__ out_inv_scale,
+                                                                 const int32_t *__restrict__ count_ptr, int n_fixed,
+                                                                 const u64 *__restrict__ side,
+                                                                 const u32x4 *__restrict__ w0h,
+                                                                 const u32x4 *__restrict__ w0l,
+                                                                 const float *__restrict__ b0) {
+    constexpr int OH = IH + 1, OW = IW + 1, IP = IH * IW, OP = OH * OW, W2 = IW + 2;
+    constexpr int RC = NB * OW;
+    static_assert(RC <= 32, "one output row of all boards must fit one 32-row MFMA tile");
+    constexpr int BS = conv_board_stride(IH, IW), LEAD = 2;
+    constexpr int NPOS = LEAD + NB * BS + 2;
+    constexpr int PB = SP_PB;
+    constexpr int REGION = (NPOS > NB * OP ? NPOS : NB * OP) * PB;   // image, later the output tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4 *lds = reinterpret_cast<u32x4 *>(smem_raw);
+    float *s_max = reinterpret_cast<float *>(smem_raw + REGION);     // [4 waves][NB]
+
+    const int count = batch_count_sp(count_ptr, n_fixed);
+    const int b0i = blockIdx.x * NB;
+    if (b0i >= count) return;
+    const int nb_valid = min(NB, count - b0i);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, nt = tid >> 6, m = lane & 31, h = lane >> 5;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    float kin[NB];                                               // 1 / (input scale * weight scale) per board
+    if constexpr (FUSE_IN) {
+        static_assert(IH == 7 && IW == 8, "the fused input layer produces 7x8 maps");
+        for (int e = tid; e < NPOS * SP_RS; e += 256) lds[e] = zero4;
+        __syncthreads();
+        // k = plane*16 + kh*4 + kw; lane half h holds k%16 in [8h, 8h+8)
+        half8 bwh[2], bwl[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            bwh[pl] = as_half8(w0h[(nt * 32 + m) * 4 + 2 * pl + h]);
+            bwl[pl] = as_half8(w0l[(nt * 32 + m) * 4 + 2 * pl + h]);
+        }
+        const float bv_in = b0[nt * 32 + m];
+        const float inv_sw0 = sc->inv_sw0, sa1 = sc->sa1;
+        _Float16 *ldsh_in = reinterpret_cast<_Float16 *>(smem_raw);
+        for (int j = 0; j < nb_valid; ++j) {
+            const u64 planes[2] = {side[2 * (b0i + j)], side[2 * (b0i + j) + 1]};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int pos = mt * 32 + m, oh = pos >> 3, ow = pos & 7;      // output cell of this MFMA row
+                f32x16 c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    half8 a;
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const int ih = oh + 2 * h + rr - 2;                    // kh = 2h + rr
+                        // bits iw = 0..6 of reference row ih: stones at bit iw*7 + (5 - ih)
+                        u64 t = (unsigned)ih < 6u ? (planes[pl] >> (5 - ih)) & c4::kBottomMask : 0;
+                        unsigned row = (unsigned)((t * 0x41041041040ULL) >> 42) & 0x7F;
+                        unsigned nib = ((row << 2) >> ow) & 0xF;               // bit kw <-> iw = ow + kw - 2
+#pragma unroll
+                        for (int kw = 0; kw < 4; ++kw) a[rr * 4 + kw] = ((nib >> kw) & 1) ? (_Float16)1.0f : (_Float16)0.0f;
+                    }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bwl[pl], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bwh[pl], c, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (p < IP) {
+                        const float v = fmaxf(__builtin_fmaf(c[r], inv_sw0, bv_in), 0.f);
+                        _Float16 hi, lo;
+                        split_half(v * sa1, hi, lo);
+                        _Float16 *dst = ldsh_in + (LEAD + j * BS + (p / IW) * W2 + p % IW) * (PB / 2) + nt * 32 + m;
+                        dst[0] = hi;
+                        dst[128] = lo;
+                    }
+                }
+            }
+        }
+        const float k = sc->inv_sa1 * sc->inv_sw2;
+        static_for<NB>([&](auto J) __attribute__((always_inline)) { kin[decltype(J)::value] = k; });
+    } else {
+        // one pass over the image: input pixels from memory, zeros everywhere else
+        const u32x4 *src = in + (size_t)b0i * IP * 32;
+        for (int e = tid; e < NPOS * 32; e += 256) {
+            const int pos = e >> 5, q = e & 31;
+            const int rel = pos - LEAD, j = rel / BS, rem = rel - j * BS, ih = rem / W2, iw = rem - ih * W2;
+            const bool data = rel >= 0 && j < nb_valid && ih < IH && iw < IW;
+            lds[pos * SP_RS + q] = data ? src[((j * IH + ih) * IW + iw) * 32 + q] : zero4;
+        }
+        const float inv_sw = sc->inv_sw4;
+        static_for<NB>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            kin[j] = (j < nb_valid ? in_inv_scale[b0i + j] : 1.0f) * inv_sw;
+        });
+    }
+    __syncthreads();
+
+    // this lane's cell of every output row: board j, column ow (lanes past the last cell repeat it)
+    int cell = sigma(m);
+    cell = cell < RC ? cell : RC - 1;
+    const int lane_base = (LEAD + (cell / OW) * BS + cell % OW) * PB + h * 16;
+
+    f32x16 acc[OH];
+#pragma unroll
+    for (int t = 0; t < OH; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const u32x4 *wlh = wph + h * 128 + nt * 32 + m;
+    const u32x4 *wll = wpl + h * 128 + nt * 32 + m;
+    u32x4 bh[BRING], bl[BRING];
+#pragma unroll
+    for (int i = 0; i < BRING - 1; ++i) { bh[i] = wlh[i * 256]; bl[i] = wll[i * 256]; }
+    u32x4 ahi[ARING], alo[ARING];
+    {
+        constexpr int T0 = rows_t0(0), NT0 = rows_t1(IH, 0) - T0;
+        const int vb = lane_base + (-2 * W2 - 2) * PB;
+#pragma unroll
+        for (int f = 0; f < ARING; ++f) {
+            const unsigned char *p = smem_raw + vb + (T0 + f % NT0) * (W2 * PB) + (f / NT0) * 32;
+            ahi[f] = *reinterpret_cast<const u32x4 *>(p);
+            alo[f] = *reinterpret_cast<const u32x4 *>(p + SP_LO);
+        }
+    }
+#define NNB_SPLIT_KH(KH)                                                                                          \
+    {                                                                                                             \
+        _Pragma("unroll 1") for (int kw = 0; kw < 3; ++kw)                                                        \
+            conv_split_body<IH, IW, ARING, BRING, KH, false>(acc, ahi, alo, bh, bl, smem_raw, lane_base, kw, wlh, wll); \
+        conv_split_body<IH, IW, ARING, BRING, KH, true>(acc, ahi, alo, bh, bl, smem_raw, lane_base, 3, wlh, wll);  \
+    }
+    NNB_SPLIT_KH(0) NNB_SPLIT_KH(1) NNB_SPLIT_KH(2) NNB_SPLIT_KH(3)
+#undef NNB_SPLIT_KH
+
+    // epilogue: bias + ReLU in float32, each board's maximum over the whole block, then hi / lo with
+    // that board's scale into the output tile [board][cell][hi 128 | lo 128] in LDS, then row-contiguous stores
+    const float bv = bias[nt * 32 + m];
+    float bmax[NB];
+    static_for<NB>([&](auto J) __attribute__((always_inline)) { bmax[decltype(J)::value] = 0.f; });
+    if (h == 0) conv_split_finish<IH, IW, NB, 0>(acc, kin, bv, bmax);
+    else conv_split_finish<IH, IW, NB, 1>(acc, kin, bv, bmax);
+    static_for<NB>([&](auto J) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        float v = bmax[j];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+        if (lane == 0) s_max[nt * NB + j] = v;
+    });
+    __syncthreads();                                             // every wave is done with the image
+    float sout[NB], sinv[NB];
+    static_for<NB>([&](auto J) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        const float mx = fmaxf(fmaxf(s_max[j], s_max[NB + j]), fmaxf(s_max[2 * NB + j], s_max[3 * NB + j]));
+        sout[j] = pow2_scale(mx, sinv[j]);
+    });
+    {
+        _Float16 *ldsh = reinterpret_cast<_Float16 *>(smem_raw);
+        if (h == 0) conv_split_store<IH, IW, NB, 0>(acc, sout, ldsh, nt * 32 + m);
+        else conv_split_store<IH, IW, NB, 1>(acc, sout, ldsh, nt * 32 + m);
+    }
+    __syncthreads();
+    u32x4 *dst = out + (size_t)b0i * OP * 32;
+    const int nchunks = nb_valid * OP * 32;
+    for (int e = tid; e < nchunks; e += 256) dst[e] = lds[(e >> 5) * SP_RS + (e & 31)];
+    float my_inv = sinv[0];                                      // selects, not an indexed read of the array
+    static_for<NB>([&](auto J) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        my_inv = tid == j ? sinv[j] : my_inv;
+    });
+    if (tid < nb_valid) out_inv_scale[b0i + tid] = my_inv;
+}
+
+// ---------------------------------------------------------------------------
+// linear 11520->1024 (network.py:36-39,46-47) with split operands, split in two halves of K.
+// Block tile (32*MTR) rows x 256 columns, 4 waves (one per SIMD); wave w owns columns 64w..64w+63
+// (two 32-column tiles) for all row tiles, so one k-step of 16 is 8 fragment reads from LDS (hi and
+// lo of up to 4 row tiles), 4 weight loads from L2 (hi and lo of 2 column tiles) and up to 24 MFMAs.
+// A slabs of 64 k (128 bytes of hi and 128 of lo per row) go global -> registers four slabs ahead and
+// registers -> LDS two slabs ahead (three LDS buffers of 32 KB, one barrier per slab).  The partial
+// sums leave the kernel in true units (x row scale x weight scale) as part[ksplit][row][1024]; the
+// heads add the halves, the bias and the ReLU.  Block order as in fc_f16_kernel: blocks that share
+// blockIdx % 8 (one XCD) cover 4 row blocks x (4 column blocks x 2 K halves).
+// ---------------------------------------------------------------------------
+constexpr int FCS_K = 11520, FCS_N = 1024, FCS_BK = 64, FCS_SPLIT = 2;
+constexpr int FCS_ROW_CHUNKS = 90 * 32;                      // 16-byte chunks per activation row
+
+template <int MTR, int BR>
+__device__ __forceinline__ void fc_split_tile(const u32x4 *__restrict__ a, const float *__restrict__ a_inv_scale,
+                                              const u32x4 *__restrict__ wph, const u32x4 *__restrict__ wpl,
+                                              const SplitScales *__restrict__ sc, float *__restrict__ part, int count,
+                                              int max_rows, u32x4 (&lds)[3][128 * 16]) {
+    const int bid = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, m = lane & 31, h = lane >> 5;
+    const int x = bid & 7, i = bid >> 3;
+    const int grp = i >> 5, ii = i & 31;
+    const int mb = (grp * 8 + x) * 4 + (ii & 3);
+    const int nb = (ii >> 2) & 3, ksp = ii >> 4;
+    const int row0 = mb * (32 * MTR);
+    if (row0 >= count) return;
+
+    constexpr int KHALF = FCS_K / FCS_SPLIT;                 // 5760
+    constexpr int NSLAB = KHALF / FCS_BK;                    // 90 slabs of 64 k = 4 k-steps each
+    constexpr int NKS = NSLAB * 4;
+    constexpr int NCH = 2 * MTR;                             // staging chunks per thread and slab (16 rows each)
+    static_assert(NSLAB % 6 == 0, "the slab loop is unrolled by 6 (3 LDS buffers x 2 register sets)");
+    const int slab0 = ksp * NSLAB;
+
+    // staging map: chunk C of a thread is row 16C + tid/16, 16-byte piece tid%16 (0-7 hi, 8-15 lo)
+    const int prow = tid >> 4, pq = tid & 15;
+    const u32x4 *abase[NCH];
+    int sdst[NCH];
+    static_for<NCH>([&](auto C) __attribute__((always_inline)) {
+        constexpr int c = decltype(C)::value;
+        const int srow = 16 * c + prow;
+        const int r = min(row0 + srow, max_rows - 1);
+        abase[c] = a + (size_t)r * FCS_ROW_CHUNKS + (pq & 7) + (pq >> 3) * 16;
+        sdst[c] = srow * 16 + (pq ^ (srow & 15));
+    });
+    auto slab_off = [&](int s) __attribute__((always_inline)) { const int sg = slab0 + s; return (sg >> 1) * 32 + (sg & 1) * 8; };
+
+    u32x4 stg[2][NCH];
+    // prologue: slabs 0 and 1 into LDS, slabs 2 and 3 in flight in the two register sets
+    static_for<NCH>([&](auto C) __attribute__((always_inline)) {
+        constexpr int c = decltype(C)::value;
+        stg[0][c] = abase[c][slab_off(0)]; stg[1][c] = abase[c][slab_off(1)];
+    });
+    static_for<NCH>([&](auto C) __attribute__((always_inline)) {
+        constexpr int c = decltype(C)::value;
+        lds[0][sdst[c]] = stg[0][c]; lds[1][sdst[c]] = stg[1][c];
+    });
+    static_for<NCH>([&](auto C) __attribute__((always_inline)) {
+        constexpr int c = decltype(C)::value;
+        stg[0][c] = abase[c][slab_off(2)]; stg[1][c] = abase[c][slab_off(3)];
+    });
+    __syncthreads();
+
+    f32x16 acc[MTR][2];
+    static_for<MTR>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[t][0][r] = 0.f; acc[t][1][r] = 0.f; }
+    });
+
+    // weight fragment of (k-step, column tile): ((kstep*2 + h)*1024 + n) * 16 bytes
+    const size_t wofs = (size_t)(ksp * KHALF / 16) * 2 * FCS_N + h * FCS_N + nb * 256 + w * 64 + m;
+    const u32x4 *wlh = wph + wofs, *wll = wpl + wofs;
+    u32x4 bh[BR][2], bl[BR][2];
+    static_for<BR - 1>([&](auto Jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(Jc)::value;
+        bh[j][0] = wlh[(size_t)j * 2 * FCS_N]; bh[j][1] = wlh[(size_t)j * 2 * FCS_N + 32];
+        bl[j][0] = wll[(size_t)j * 2 * FCS_N]; bl[j][1] = wll[(size_t)j * 2 * FCS_N + 32];
+    });
+    // fragment read offsets (16-byte units) for row tile t: row 32t + m, piece (2*kstep + h) [+8 for lo]
+    int arow[MTR], asw[MTR];
+    u32x4 fh[2][MTR], fl[2][MTR];
+    static_for<MTR>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+        arow[t] = (t * 32 + m) * 16; asw[t] = (t * 32 + m) & 15;
+        fh[0][t] = lds[0][arow[t] + (h ^ asw[t])];
+        fl[0][t] = lds[0][arow[t] + ((8 + h) ^ asw[t])];
+    });
+
+    for (int s6 = 0; s6 < NSLAB; s6 += 6) {
+        static_for<6>([&](auto Uc) __attribute__((always_inline)) {
+            constexpr int U = decltype(Uc)::value;
+            const int s = s6 + U;
+            constexpr int buf = U % 3, set = U & 1;
+            static_for<4>([&](auto Kc) __attribute__((always_inline)) {
+                constexpr int ks = decltype(Kc)::value;
+                constexpr int J = U * 4 + ks;                    // k-step inside the 24-step body
+                constexpr int cur = J & 1, nxt = cur ^ 1;
+                constexpr int slot = J % BR, fill = (J + BR - 1) % BR;
+                int knext = s * 4 + ks + BR - 1;
+                knext = knext < NKS ? knext : NKS - 1;
+                constexpr int nbuf = ks < 3 ? buf : (U + 1) % 3; // where the next k-step's fragments live
+                constexpr int nks = (ks + 1) & 3;
+                const bool have_next = ks < 3 || s + 1 < NSLAB;
+                static_for<MTR>([&](auto T) __attribute__((always_inline)) {
+                    constexpr int t = decltype(T)::value;
+                    static_for<2>([&](auto Uu) __attribute__((always_inline)) {
+                        constexpr int u = decltype(Uu)::value;
+                        const half8 xh = as_half8(fh[cur][t]), xl = as_half8(fl[cur][t]);
+                        const half8 wh = as_half8(bh[slot][u]), wl = as_half8(bl[slot][u]);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, acc[t][u], 0, 0, 0);
+                        // two memory instructions behind every MFMA triple
+                        if constexpr (t == 0) {                  // weights of k-step J + BR - 1
+                            bh[fill][u] = wlh[(size_t)knext * 2 * FCS_N + 32 * u];
+                            bl[fill][u] = wll[(size_t)knext * 2 * FCS_N + 32 * u];
+                        }
+                        if constexpr (u == 1) {                  // fragments of the next k-step, row tile t
+                            if (have_next) {
+                                fh[nxt][t] = lds[nbuf][arow[t] + ((2 * nks + h) ^ asw[t])];
+                                fl[nxt][t] = lds[nbuf][arow[t] + ((8 + 2 * nks + h) ^ asw[t])];
+                            }
+                        }
+                        if constexpr (u == 0 && ks < 2) {        // slab s+2: registers -> LDS
+                            constexpr int c = ks * MTR + t;
+                            if (s + 2 < NSLAB) lds[(U + 2) % 3][sdst[c]] = stg[set][c];
+                        }
+                        if constexpr (u == 0 && ks >= 2) {       // slab s+4: global -> registers
+                            constexpr int c = (ks - 2) * MTR + t;
+                            if (s + 4 < NSLAB) stg[set][c] = abase[c][slab_off(s + 4)];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+            });
+            __syncthreads();
+        });
+    }
+
+    // epilogue: back to true units with the row's activation scale and the layer's weight scale
+    const float inv_sw = sc->inv_swf;
+    float *obase = part + (size_t)ksp * max_rows * FCS_N + nb * 256 + w * 64 + m;
+    static_for<MTR>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < count) {
+                const float k = a_inv_scale[row] * inv_sw;
+                obase[(size_t)row * FCS_N] = acc[t][0][r] * k;
+                obase[(size_t)row * FCS_N + 32] = acc[t][1][r] * k;
+            }
+        }
+    });
+}
+
+__global__ __launch_bounds__(256, 1) void fc_split_kernel(const u32x4 *__restrict__ a,          // [rows][90][32 chunks]
+                                                          const float *__restrict__ a_inv_scale, // [rows]
+                                                          const u32x4 *__restrict__ wph, const u32x4 *__restrict__ wpl,
+                                                          const SplitScales *__restrict__ sc,
+                                                          float *__restrict__ part,              // [2][max_rows][1024]
+                                                          const int32_t *__restrict__ count_ptr, int n_fixed,
+                                                          int max_rows) {
+    __shared__ __attribute__((aligned(16))) u32x4 lds[3][128 * 16];     // 128 rows x (64 hi + 64 lo halves), 3 buffers
+    const int count = batch_count_sp(count_ptr, n_fixed);
+    const int mblocks = gridDim.x >> 3;                      // row blocks the grid provides (8 column/K blocks each)
+    const int tiles = (count + 32 * mblocks - 1) / (32 * mblocks);
+    if (tiles <= 1) fc_split_tile<1, 4>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds);
+    else if (tiles == 2) fc_split_tile<2, 4>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds);
+    else if (tiles == 3) fc_split_tile<3, 4>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds);
+    else fc_split_tile<4, 4>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds);
+}
+
+// Activations of the split path back to float32 [n][cells][128] (tests and debugging only).
+__global__ void split_to_f32_kernel(const _Float16 *__restrict__ act, const float *__restrict__ inv_scale,
+                                    int cells, int n, float *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n * cells * 128) return;
+    const size_t pos = i >> 7;
+    const int ch = (int)(i & 127);
+    const size_t board = pos / cells;
+    out[i] = ((float)act[pos * 256 + ch] + (float)act[pos * 256 + 128 + ch]) * inv_scale[board];
+}
+
+// ---------------------------------------------------------------------------
+// Host launchers
+// ---------------------------------------------------------------------------
+static inline int cdiv_sp(int a, int b) { return (a + b - 1) / b; }
+
+constexpr int CS_NB = 3;
+constexpr size_t C2S_SPLIT_LDS = conv_split_lds_bytes(7, 8, CS_NB);
+constexpr size_t C4S_SPLIT_LDS = conv_split_lds_bytes(8, 9, CS_NB);
+static_assert(C4S_SPLIT_LDS <= 160 * 1024, "the image of one block must fit the LDS of a CU");
+
+hipError_t prepare_net_kernels_split() {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rows_split_kernel<7, 8, CS_NB, 4, 8, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)C2S_SPLIT_LDS);
+    if (err != hipSuccess) return err;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rows_split_kernel<8, 9, CS_NB, 4, 8, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C4S_SPLIT_LDS);
+}
+
+void launch_repack_split(hipStream_t st, const NetWeights &dst, const float *conv0_w, const float *conv0_b,
+                         const float *conv2_w, const float *conv4_w, const float *fc_w) {
+    unsigned *mx = reinterpret_cast<unsigned *>(dst.sp_maxbits);
+    (void)hipMemsetAsync(mx, 0, 4 * sizeof(unsigned), st);
+    absmax_kernel<<<4, 256, 0, st>>>(conv0_w, 128 * 32, mx + 0);
+    absmax_kernel<<<64, 256, 0, st>>>(conv2_w, 128 * 128 * 16, mx + 1);
+    absmax_kernel<<<64, 256, 0, st>>>(conv4_w, 128 * 128 * 16, mx + 2);
+    absmax_kernel<<<1024, 256, 0, st>>>(fc_w, (size_t)1024 * 11520, mx + 3);
+    split_scales_kernel<<<1, 64, 0, st>>>(mx, conv0_w, conv0_b, dst.sp_scales);
+    repack_conv0_split_kernel<<<cdiv_sp(128 * 32, 256), 256, 0, st>>>(conv0_w, &dst.sp_scales->sw0, (_Float16 *)dst.conv0_wh,
+                                                                      (_Float16 *)dst.conv0_wl);
+    repack_conv_split_kernel<<<cdiv_sp(128 * 128 * 16, 256), 256, 0, st>>>(conv2_w, &dst.sp_scales->sw2, (_Float16 *)dst.conv2_wh,
+                                                                           (_Float16 *)dst.conv2_wl);
+    repack_conv_split_kernel<<<cdiv_sp(128 * 128 * 16, 256), 256, 0, st>>>(conv4_w, &dst.sp_scales->sw4, (_Float16 *)dst.conv4_wh,
+                                                                           (_Float16 *)dst.conv4_wl);
+    repack_fc_split_kernel<<<(1024 * 11520) / 256, 256, 0, st>>>(fc_w, &dst.sp_scales->swf, (_Float16 *)dst.fc_wh,
+                                                                 (_Float16 *)dst.fc_wl);
+}
+
+void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, const NetBuffers &b, const u64 *side,
+                            const uint8_t *legal, float *logp_out, float *value_out, float *prior_out,
+                            const int32_t *count_ptr, int n_max) {
+    if (n_max <= 0) return;
+    u32x4 *a2 = reinterpret_cast<u32x4 *>(b.act2), *a3 = reinterpret_cast<u32x4 *>(b.act3);
+    switch (stage) {
+    case NET_CONV0:
+        break;      // fused into the first 128->128 layer below
+    case NET_CONV2:
+        conv_rows_split_kernel<7, 8, CS_NB, 4, 8, true><<<cdiv_sp(n_max, CS_NB), 256, C2S_SPLIT_LDS, st>>>(
+            nullptr, nullptr, (const u32x4 *)w.conv2_wh, (const u32x4 *)w.conv2_wl, w.conv2_b, w.sp_scales, a2,
+            b.act2_inv, count_ptr, n_max, side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b);
+        break;
+    case NET_CONV4:
+        conv_rows_split_kernel<8, 9, CS_NB, 4, 8, false><<<cdiv_sp(n_max, CS_NB), 256, C4S_SPLIT_LDS, st>>>(
+            a2, b.act2_inv, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b, w.sp_scales, a3,
+            b.act3_inv, count_ptr, n_max, nullptr, nullptr, nullptr, nullptr);
+        break;
+    case NET_FC: {
+        int groups = cdiv_sp(cdiv_sp(n_max, 128), 32);       // 32 row blocks per group of 256 blocks
+        fc_split_kernel<<<256 * groups, 256, 0, st>>>(a3, b.act3_inv, (const u32x4 *)w.fc_wh, (const u32x4 *)w.fc_wl,
+                                                      w.sp_scales, b.fcpart, count_ptr, n_max, b.max_rows);
+        break;
+    }
+    case NET_HEADS:     // partial sums have the layout of the half-input path: its heads kernel serves both
+        launch_net_stage_f16(st, NET_HEADS, w, b, side, legal, logp_out, value_out, prior_out, count_ptr, n_max);
+        break;
+    default: break;
+    }
+}
+
+void launch_split_to_f32(hipStream_t st, const void *act, const float *inv_scale, int cells, int n, float *out) {
+    if (n <= 0) return;
+    const size_t total = (size_t)n * cells * 128;
+    split_to_f32_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const _Float16 *)act, inv_scale, cells, n, out);
+}
+
+}  // namespace nnb

@@ -140,6 +140,20 @@ size_t carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std:
         b.act1_b1 = two ? c.take<float>(G * 56 * 128) : nullptr;
         b.act2_b1 = two ? c.take<float>(G * 72 * 128) : nullptr;
         b.act3_b1 = two ? c.take<float>(G * 90 * 128) : nullptr;
+    } else if (cfg.net_precision == NNB_NET_F32S) {      // hi + lo halves: 4 bytes per value, plus a scale per board
+        const bool two = cfg.n_weight_sets > 1;
+        b.act1 = b.act1_b1 = nullptr;
+        b.fc = b.fc_b1 = nullptr;
+        b.act2 = c.take<float>(G * 72 * 128);
+        b.act3 = c.take<float>(G * 90 * 128);
+        b.act2_inv = c.take<float>(G);
+        b.act3_inv = c.take<float>(G);
+        b.fcpart = c.take<float>(2 * G * 1024);
+        b.fcpart_b1 = c.take<float>(2 * G * 1024);
+        b.act2_b1 = two ? c.take<float>(G * 72 * 128) : nullptr;
+        b.act3_b1 = two ? c.take<float>(G * 90 * 128) : nullptr;
+        b.act2_inv_b1 = two ? c.take<float>(G) : nullptr;
+        b.act3_inv_b1 = two ? c.take<float>(G) : nullptr;
     } else {                                // half activations; the 2->128 layer's output stays in LDS
         b.act1 = nullptr;
         b.act2 = reinterpret_cast<float *>(c.take<uint16_t>(G * 72 * 128));
@@ -157,6 +171,7 @@ size_t carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std:
     for (auto &s : w) {
         s.conv0_w = c.take<float>(128 * 32);  s.conv0_b = c.take<float>(128);
         const bool f32 = cfg.net_precision == NNB_NET_F32;
+        const bool split = cfg.net_precision == NNB_NET_F32S;
         s.conv2_b = c.take<float>(128); s.conv4_b = c.take<float>(128); s.fc_b = c.take<float>(1024);
         s.conv2_w = f32 ? c.take<float>(128 * 128 * 16) : nullptr;
         s.conv4_w = f32 ? c.take<float>(128 * 128 * 16) : nullptr;
@@ -164,6 +179,13 @@ size_t carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std:
         s.conv2_wh = f32 ? nullptr : (void *)c.take<uint16_t>(128 * 128 * 16);
         s.conv4_wh = f32 ? nullptr : (void *)c.take<uint16_t>(128 * 128 * 16);
         s.fc_wh = f32 ? nullptr : (void *)c.take<uint16_t>((size_t)1024 * 11520);
+        s.conv2_wl = split ? (void *)c.take<uint16_t>(128 * 128 * 16) : nullptr;
+        s.conv4_wl = split ? (void *)c.take<uint16_t>(128 * 128 * 16) : nullptr;
+        s.fc_wl = split ? (void *)c.take<uint16_t>((size_t)1024 * 11520) : nullptr;
+        s.conv0_wh = split ? (void *)c.take<uint16_t>(128 * 32) : nullptr;
+        s.conv0_wl = split ? (void *)c.take<uint16_t>(128 * 32) : nullptr;
+        s.sp_scales = split ? c.take<SplitScales>(1) : nullptr;
+        s.sp_maxbits = split ? (void *)c.take<uint32_t>(4) : nullptr;
         s.heads_w = c.take<float>(8 * 1024);  s.heads_b = c.take<float>(8);
     }
     c.take<unsigned char>(kAlign);          // tail pad
@@ -178,7 +200,7 @@ int check_cfg(const nnb_config *cfg) {
         return fail(NNB_ERR_ARG, "max_sims %d out of range [1, %d]", cfg->max_sims, kMaxSims);
     if (cfg->n_weight_sets < 1 || cfg->n_weight_sets > 8)
         return fail(NNB_ERR_ARG, "n_weight_sets %d out of range [1, 8]", cfg->n_weight_sets);
-    if (cfg->net_precision != NNB_NET_F16 && cfg->net_precision != NNB_NET_F32)
+    if (cfg->net_precision != NNB_NET_F16 && cfg->net_precision != NNB_NET_F32 && cfg->net_precision != NNB_NET_F32S)
         return fail(NNB_ERR_ARG, "net_precision %d out of range", cfg->net_precision);
     const int cs = cfg->eval_cache_slots;
     if (cs != 0 && (cs < 0 || cs > 65536 || (cs & (cs - 1)) != 0))
@@ -269,6 +291,8 @@ void net_stage(nnb_engine *e, hipStream_t st, int stage, const NetWeights &w, co
                const uint8_t *legal, float *logp, float *value, float *prior, const int32_t *count_ptr, int n_max) {
     if (e->cfg.net_precision == NNB_NET_F32)
         launch_net_stage(st, stage, w, b, side, legal, logp, value, prior, count_ptr, n_max);
+    else if (e->cfg.net_precision == NNB_NET_F32S)
+        launch_net_stage_split(st, stage, w, b, side, legal, logp, value, prior, count_ptr, n_max);
     else
         launch_net_stage_f16(st, stage, w, b, side, legal, logp, value, prior, count_ptr, n_max);
 }
@@ -280,6 +304,7 @@ NetBuffers batch_buffers(const nnb_engine *e, int batch) {
     if (batch == 1) {
         b.fc = b.fc_b1; b.fcpart = b.fcpart_b1;
         b.act1 = b.act1_b1; b.act2 = b.act2_b1; b.act3 = b.act3_b1;
+        b.act2_inv = b.act2_inv_b1; b.act3_inv = b.act3_inv_b1;
     }
     return b;
 }
@@ -298,7 +323,7 @@ void forward_leaves(nnb_engine *e, hipStream_t st, int weight_set, int batch, in
     const EngineDev &d = e->dev;
     const NetBuffers nb = batch_buffers(e, batch);
     const size_t o = (size_t)batch * d.max_games;
-    const bool fused_in = e->cfg.net_precision == NNB_NET_F16;     // conv0 is part of the conv2 launch there
+    const bool fused_in = e->cfg.net_precision != NNB_NET_F32;     // conv0 is part of the conv2 launch there
     if (!fused_in) { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, nb, d.leaf_side + 2 * o, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
     { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, nb, d.leaf_side + 2 * o, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
     { ProfScope ps(e, 3, st); net_stage(e, st, NET_CONV4, w, nb, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
@@ -408,6 +433,17 @@ int collect_stats(nnb_engine *e, hipStream_t st, nnb_round_stats *out, long long
         out->moves_rounds = rounds;
     }
     return NNB_OK;
+}
+
+// Layer outputs in whatever form the engine's arithmetic keeps them -> float32 (nnb_debug_activations).
+// kind 0: float32 copy; 1: halves; 2: ReLU(part0 + part1 + bias) of the split linear layer.
+__global__ void debug_act_kernel(int kind, const void *src, const float *src2, const float *bias, size_t total,
+                                 float *out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    if (kind == 0) out[i] = static_cast<const float *>(src)[i];
+    else if (kind == 1) out[i] = (float)static_cast<const _Float16 *>(src)[i];
+    else out[i] = fmaxf((static_cast<const float *>(src)[i] + src2[i]) + bias[i & 1023], 0.f);
 }
 
 // ---- search state of nnb_search_static: one fixed array per GPU, no allocation ----------------
@@ -526,6 +562,7 @@ int nnb_engine_create(const nnb_config *cfg, void *workspace, size_t workspace_b
     HIP_TRY(prepare_net_kernels());
     HIP_TRY(prepare_tree_step());
     HIP_TRY(prepare_net_kernels_f16());
+    HIP_TRY(prepare_net_kernels_split());
     HIP_TRY(hipStreamSynchronize(st));
     guard.e = nullptr;
     *engine_out = e;
@@ -560,6 +597,8 @@ int nnb_load_weights(nnb_engine *e, int weight_set, void *stream, const float *c
     launch_repack(st, e->weights[weight_set], conv0_w, conv0_b, conv2_w, conv2_b, conv4_w, conv4_b, fc_w, fc_b,
                   policy_w, policy_b, value_w, value_b);
     if (e->cfg.net_precision == NNB_NET_F16) launch_repack_f16(st, e->weights[weight_set], conv2_w, conv4_w, fc_w);
+    if (e->cfg.net_precision == NNB_NET_F32S)
+        launch_repack_split(st, e->weights[weight_set], conv0_w, conv0_b, conv2_w, conv4_w, fc_w);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     e->weights_loaded[weight_set] = 1;
@@ -642,6 +681,34 @@ int nnb_net_forward_planes(nnb_engine *e, int weight_set, void *stream, int32_t 
     launch_planes_to_bits(st, n, planes, e->dev.leaf_side);
     return nnb_net_forward(e, weight_set, stream, n, reinterpret_cast<const uint64_t *>(e->dev.leaf_side), nullptr,
                            log_policy_out, value_out, nullptr);
+}
+
+int nnb_debug_activations(nnb_engine *e, int weight_set, void *stream, int layer, int32_t n, float *out) {
+    if (!e) return fail(NNB_ERR_ARG, "engine is null");
+    if (n < 0 || n > e->cfg.max_games) return fail(NNB_ERR_ARG, "n = %d out of range [0, %d]", n, e->cfg.max_games);
+    if (weight_set < 0 || weight_set >= e->cfg.n_weight_sets) return fail(NNB_ERR_ARG, "weight_set out of range");
+    if (layer < 2 || layer > 4) return fail(NNB_ERR_ARG, "layer %d: 2 and 3 are the 128->128 convolutions, 4 the linear layer", layer);
+    if (n == 0) return NNB_OK;
+    if (!out) return fail(NNB_ERR_ARG, "out is null");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const NetBuffers &b = e->buf;
+    const int prec = e->cfg.net_precision;
+    if (layer == 4) {
+        const size_t total = (size_t)n * 1024;
+        const unsigned blocks = (unsigned)((total + 255) / 256);
+        if (prec == NNB_NET_F32) debug_act_kernel<<<blocks, 256, 0, st>>>(0, b.fc, nullptr, nullptr, total, out);
+        else debug_act_kernel<<<blocks, 256, 0, st>>>(2, b.fcpart, b.fcpart + (size_t)b.max_rows * 1024,
+                                                      e->weights[weight_set].fc_b, total, out);
+    } else {
+        const int cells = layer == 2 ? 72 : 90;
+        const float *act = layer == 2 ? b.act2 : b.act3;
+        const size_t total = (size_t)n * cells * 128;
+        const unsigned blocks = (unsigned)((total + 255) / 256);
+        if (prec == NNB_NET_F32S) launch_split_to_f32(st, act, layer == 2 ? b.act2_inv : b.act3_inv, cells, n, out);
+        else debug_act_kernel<<<blocks, 256, 0, st>>>(prec == NNB_NET_F32 ? 0 : 1, act, nullptr, nullptr, total, out);
+    }
+    HIP_TRY(hipGetLastError());
+    return NNB_OK;
 }
 
 int nnb_search(nnb_engine *e, void *stream, const nnb_search_params *params, int32_t n,

@@ -200,6 +200,16 @@ class Engine:
                                                   _ptr(logp), _ptr(value)), "nnb_net_forward_planes")
         return logp, value
 
+    def activations(self, layer: int, n: int, weight_set: int = 0) -> torch.Tensor:
+        """Hidden activations of the last net_forward call as float32: layer 2 -> [n,8,9,128],
+        3 -> [n,9,10,128] (row, column, channel), 4 -> [n,1024].  Test hook."""
+        shape = {2: (n, 8, 9, 128), 3: (n, 9, 10, 128), 4: (n, 1024)}[layer]
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.nnb_debug_activations(self.handle, weight_set, self._stream(), layer, n, _ptr(out)),
+                  "nnb_debug_activations")
+        return out
+
     # ------------------------------------------------------------------ K2 / K7
     def search(self, colour_boards, players, params: SearchParams, root_noise=None, side_players=None):
         """One search per root.  Returns (visits int32[n,7], action int8[n], root_value f64[n], stats).

@@ -43,8 +43,11 @@ FLOP_PER_LEAF = {
     "fc": 2 * 11520 * 1024,
     "heads": 2 * 1024 * 8,
 }
-PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}      # MI355X dense matrix peaks (half inputs / f32 inputs)
-DTYPE_NAME = {"f16": "f16 (f32 accumulate)", "f32": "f32"}
+# MI355X dense matrix peaks of the MFMA instruction each path issues.  "f32s" issues half-input MFMAs, three
+# per float32 product; its FLOPs are counted once per product, so at best a third of that peak is reachable.
+PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f32s": 2500.0}
+DTYPE_NAME = {"f16": "f16 (f32 accumulate)", "f32": "f32",
+              "f32s": "f32 (each operand a hi+lo pair of halves, 3 half-input MFMAs per product, f32 accumulate)"}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -86,7 +89,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--games", type=int, default=GAMES_PER_GPU, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=SIMS)
-    ap.add_argument("--precision", choices=["f16", "f32"], default="f16",
+    ap.add_argument("--precision", choices=["f16", "f32", "f32s"], default="f32s",
                     help="arithmetic of the network's conv / linear layers (both accumulate in f32)")
     ap.add_argument("--opening-plies", type=int, default=0,
                     help="random legal moves played before self-play starts (0 = every game from the empty board, as the\n"

@@ -90,12 +90,15 @@ enum nnb_flags {
     NNB_FLAG_EVAL_CACHE = 8
 };
 
-/* How the network's three big layers multiply.  Both accumulate in float32 and keep bias,
+/* How the network's three big layers multiply.  All accumulate in float32 and keep bias,
  * ReLU, heads, log-softmax and tanh in float32.
- *   NNB_NET_F16: activations and weights rounded to IEEE half, v_mfma_f32_32x32x16_f16
- *                (about 1e-5 absolute from the float32 forward on the default network);
- *   NNB_NET_F32: float32 inputs, v_mfma_f32_32x32x2_f32 (exact f32 FMA chains, 1/16 the rate). */
-enum nnb_precision { NNB_NET_F16 = 0, NNB_NET_F32 = 1 };
+ *   NNB_NET_F16 : activations and weights rounded to IEEE half, v_mfma_f32_32x32x16_f16
+ *                 (about 1e-5 absolute from the float32 forward on the default network);
+ *   NNB_NET_F32 : float32 inputs, v_mfma_f32_32x32x2_f32 (exact f32 FMA chains, 1/16 the rate);
+ *   NNB_NET_F32S: float32-faithful on the half-input matrix cores: every float32 operand is carried as
+ *                 a scaled hi + lo pair of halves (2^-22 relative), three MFMAs per product, a third of
+ *                 the NNB_NET_F16 rate; as close to the float32 forward as NNB_NET_F32 is. */
+enum nnb_precision { NNB_NET_F16 = 0, NNB_NET_F32 = 1, NNB_NET_F32S = 2 };
 
 typedef struct nnb_config {
     int32_t max_games;   /* concurrent games / root positions per call (>= 1)      */
@@ -228,6 +231,13 @@ int nnb_net_forward(nnb_engine *engine, int weight_set, void *stream, int32_t n,
 /* Same from float32 planes [n,2,6,7] whose entries are exactly 0 or 1. */
 int nnb_net_forward_planes(nnb_engine *engine, int weight_set, void *stream, int32_t n,
                            const float *planes, float *log_policy_out, float *value_out);
+
+/* Test hook: the hidden activations the last nnb_net_forward / nnb_net_forward_planes call left in the
+ * engine for its first n positions, converted to float32 whatever the engine's arithmetic: layer 2 =
+ * ReLU(conv_layers.2) as [n][8][9][128] (row, column, channel), layer 3 = ReLU(conv_layers.4) as
+ * [n][9][10][128], layer 4 = ReLU(fc_layers.0) as [n][1024] (network.py:31-39,45-47).
+ * No counterpart in the reference (torch keeps these inside forward). */
+int nnb_debug_activations(nnb_engine *engine, int weight_set, void *stream, int layer, int32_t n, float *out);
 
 /* ---- baseline opponent ---------------------------------------------------- */
 /* MinimaxAgent.select_move (nnbattle/agents/minimax/agent_code.py:23-89, position score of

@@ -41,10 +41,11 @@ def oracle():
     return co, rp
 
 
-@pytest.fixture(scope="module", params=["f16", "f32"])
+@pytest.fixture(scope="module", params=["f16", "f32", "f32s"])
 def seed0_engine(request, torch_mod, oracle):
     """Engines with the seed-0 network loaded, one per network arithmetic: half inputs on
-    v_mfma_f32_32x32x16_f16 (the default) and float32 inputs on v_mfma_f32_32x32x2_f32."""
+    v_mfma_f32_32x32x16_f16, float32 inputs on v_mfma_f32_32x32x2_f32, and float32 operands carried as
+    hi + lo pairs of halves (three MFMAs per product)."""
     from alphazero_amd.engine import Engine
     _, rp = oracle
     eng = Engine(max_games=512, max_sims=200, precision=request.param)
@@ -54,7 +55,7 @@ def seed0_engine(request, torch_mod, oracle):
 
 
 # max |device - reference CPU float32| allowed in practice per arithmetic (the task's bar is 1e-3)
-TIGHT = {"f32": 5e-5, "f16": 2e-4}
+TIGHT = {"f32": 5e-6, "f32s": 5e-6, "f16": 2e-4}
 
 
 def _random_positions(rp, co, n, seed, max_plies=36, allow_terminal=False):
@@ -352,6 +353,30 @@ def test_net_forward_golden(seed0_engine, oracle):
           "max |dvalue|", np.abs(value - z["value"]).max())
 
 
+def test_net_hidden_activations_match_the_cpu_layers(seed0_engine, oracle, torch_mod):
+    """Layer by layer against torch's float32 CPU layers (network.py:31-39,45-47): the two 128->128
+    convolutions and the linear layer, relative to each layer's largest activation."""
+    torch = torch_mod
+    import torch.nn.functional as F
+    co, rp = oracle
+    sd = rp.seeded_state_dict(0)
+    z = np.load(os.path.join(GOLDEN, "net_seed0.npz"))
+    n = 100                                                     # not a multiple of any kernel's board tile
+    planes = torch.from_numpy(np.stack([rp.planes(b, int(m)) for b, m in zip(z["boards"][:n], z["me"][:n])]))
+    with torch.no_grad():
+        a1 = F.relu(F.conv2d(planes, sd["conv_layers.0.weight"], sd["conv_layers.0.bias"], padding=2))
+        a2 = F.relu(F.conv2d(a1, sd["conv_layers.2.weight"], sd["conv_layers.2.bias"], padding=2))
+        a3 = F.relu(F.conv2d(a2, sd["conv_layers.4.weight"], sd["conv_layers.4.bias"], padding=2))
+        a4 = F.relu(F.linear(a3.reshape(n, -1), sd["fc_layers.0.weight"], sd["fc_layers.0.bias"]))
+    seed0_engine.net_forward_planes(planes)
+    rel = {"f16": 2e-3, "f32": 1e-5, "f32s": 1e-5}[seed0_engine.precision]
+    for layer, want in ((2, a2.permute(0, 2, 3, 1)), (3, a3.permute(0, 2, 3, 1)), (4, a4)):
+        got = seed0_engine.activations(layer, n).cpu()
+        err = (got - want).abs().max().item() / want.abs().max().item()
+        print(seed0_engine.precision, "layer", layer, "max error / max activation:", err)
+        assert err < rel, (layer, err)
+
+
 def test_net_forward_planes_and_ragged_batches(seed0_engine, oracle, torch_mod):
     torch = torch_mod
     co, rp = oracle
@@ -384,9 +409,12 @@ def test_net_search_matches_cpu_reference_game(seed0_engine, oracle, net_golden_
     agree = sum(int(visits[i].tolist() == g["visits"][i]) for i in range(len(boards)))
     assert visits.sum(axis=1).tolist() == [99] * len(boards)
     print(seed0_engine.precision, "plies with identical visit vectors:", agree, "of", len(boards))
-    need = 0.75 if seed0_engine.precision == "f32" else 0.5
-    assert agree >= int(need * len(boards)), (agree, len(boards))
-    assert action.tolist()[:4] == g["moves"][:4]
+    if seed0_engine.precision == "f16":
+        assert agree >= len(boards) // 2, (agree, len(boards))
+        assert action.tolist()[:4] == g["moves"][:4]
+    else:           # the float32-faithful arithmetics reproduce the reference's game ply for ply
+        assert agree == len(boards), (agree, len(boards))
+        assert action.tolist() == g["moves"]
 
 
 def test_net_search_sided_positions(seed0_engine, oracle, sided_golden):
