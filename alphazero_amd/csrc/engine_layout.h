@@ -93,6 +93,11 @@ struct RoundDev {
 constexpr int kRefills = 16;    // index into EngineDev::counters; entries 0..15 are cleared every move
 constexpr int kLive = 17;       // slots that still hold a game (kept through a whole round)
 
+// Games [first, end) and the leaf batch they file their leaves in (-1: by the root mover's weight set).
+struct GameSpan {
+    int32_t first, end, batch;
+};
+
 struct SearchDev {
     int32_t mode;
     int32_t evaluator;

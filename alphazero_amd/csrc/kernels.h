@@ -24,14 +24,15 @@ struct HeadsPair {
     int32_t fused;
 };
 void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, int parity, const HeadsPair &heads,
-                      const RoundDev *turnover = nullptr);
+                      const RoundDev *turnover = nullptr, const GameSpan *span = nullptr);
 hipError_t prepare_tree_fused(size_t lds_bytes);
 hipError_t prepare_tree_step();
 void launch_tree_fused(hipStream_t st, const EngineDev &e, const SearchDev &p, size_t lds_bytes);
 void launch_readout(hipStream_t st, const EngineDev &e, const SearchDev &p, int32_t *visits_out,
                     int8_t *action_out, double *root_value_out, const RoundDev *round);
 void launch_selfplay_init(hipStream_t st, const EngineDev &e, const RoundDev &round);
-void launch_turnover(hipStream_t st, const EngineDev &e, const SearchDev &p, const RoundDev &round, int make_noise);
+void launch_turnover(hipStream_t st, const EngineDev &e, const SearchDev &p, const RoundDev &round, int make_noise,
+                     const GameSpan *span = nullptr);
 void launch_search_init(hipStream_t st, const EngineDev &e, const u64 *boards, const int8_t *players,
                         const int8_t *sides, int game_base, const float *root_noise);
 void launch_dirichlet_noise(hipStream_t st, int n, u64 seed, const int32_t *game_ids, const int32_t *move_index,

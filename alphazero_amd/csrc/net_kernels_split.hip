@@ -123,89 +123,135 @@ __global__ void repack_conv0_split_kernel(const float *__restrict__ w, const flo
 // leaf encode (AlphaZeroAgent.preprocess, agent_code.py:76-89) and the 2->128 convolution
 // (network.py:29-30) from the side boards, with the layer's static output scale.
 // ---------------------------------------------------------------------------
-template <int IH, int IW, int ARING, int BRING, int KH, bool LAST>
-__device__ __forceinline__ void conv_split_body(f32x16 (&acc)[IH + 1], u32x4 (&ahi)[ARING], u32x4 (&alo)[ARING],
-                                                u32x4 (&bh)[BRING], u32x4 (&bl)[BRING], const unsigned char *smem,
-                                                int lane_base, int kw, const u32x4 *__restrict__ wlh,
-                                                const u32x4 *__restrict__ wll) {
+// All four taps of kernel row KH.  The code of a block should stay resident in the instruction cache (64 KB
+// shared by two CUs; straight-line code that misses it runs at ~20 cycles per instruction), so there is ONE
+// body per kernel row: the tap loop is a real loop, the fragment ring is refilled across taps under a uniform
+// predicate and primed again at the start of each kernel row.
+template <int IH, int IW, int ARING, int BRING, int KH>
+__device__ __forceinline__ void conv_split_row(f32x16 (&acc)[IH + 1], u32x4 (&bh)[BRING], u32x4 (&bl)[BRING],
+                                               const unsigned char *smem, int lane_base,
+                                               const u32x4 *__restrict__ wlh, const u32x4 *__restrict__ wll) {
     constexpr int W2 = IW + 2, PB = SP_PB;
     constexpr int T0 = rows_t0(KH), NT = rows_t1(IH, KH) - T0, STEPS = 8 * NT;
-    constexpr int KHN = LAST ? KH + 1 : KH;                      // kernel row of the body that runs next
-    constexpr bool HAS_NEXT = !(LAST && KH == 3);
-    constexpr int T0N = rows_t0(KHN & 3), NTN = rows_t1(IH, KHN & 3) - T0N;
     static_assert(STEPS % ARING == 0, "ring depth must divide the fragment pairs per tap");
-    const int vb = lane_base + ((KH - 2) * W2 + kw - 2) * PB;
-    const int vbn = LAST ? lane_base + ((KHN - 2) * W2 - 2) * PB : vb + PB;
-    const int step0 = (KH * 4 + kw) * 8;
+    u32x4 ahi[ARING], alo[ARING];
+    {
+        const unsigned char *p0 = smem + lane_base + ((KH - 2) * W2 - 2) * PB;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        {                                                        // weights BRING-1 k-steps ahead
-            int nxt = step0 + ks + BRING - 1;
-            nxt = nxt < 128 ? nxt : 127;
-            bh[(ks + BRING - 1) & (BRING - 1)] = wlh[nxt * 256];
-            bl[(ks + BRING - 1) & (BRING - 1)] = wll[nxt * 256];
+        for (int f = 0; f < ARING; ++f) {
+            const unsigned char *p = p0 + (T0 + f % NT) * (W2 * PB) + (f / NT) * 32;
+            ahi[f] = *reinterpret_cast<const u32x4 *>(p);
+            alo[f] = *reinterpret_cast<const u32x4 *>(p + SP_LO);
         }
-        const half8 wh = as_half8(bh[ks & (BRING - 1)]), wl = as_half8(bl[ks & (BRING - 1)]);
+    }
+#pragma unroll 1
+    for (int kw = 0; kw < 4; ++kw) {
+        const unsigned char *pv = smem + lane_base + ((KH - 2) * W2 + kw - 2) * PB;
+        const bool more = kw < 3;                                // uniform: another tap of this kernel row follows
+        const int step0 = (KH * 4 + kw) * 8;
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const int f = ks * NT + i, g = f + ARING;
-            const half8 xh = as_half8(ahi[f % ARING]), xl = as_half8(alo[f % ARING]);
-            acc[T0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, acc[T0 + i], 0, 0, 0);
-            acc[T0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, acc[T0 + i], 0, 0, 0);
-            acc[T0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, acc[T0 + i], 0, 0, 0);
-            if (g < STEPS) {
-                const unsigned char *p = smem + vb + (T0 + g % NT) * (W2 * PB) + (g / NT) * 32;
-                ahi[g % ARING] = *reinterpret_cast<const u32x4 *>(p);
-                alo[g % ARING] = *reinterpret_cast<const u32x4 *>(p + SP_LO);
-            } else if (HAS_NEXT) {
-                const int gg = g - STEPS;
-                const unsigned char *p = smem + vbn + (T0N + gg % NTN) * (W2 * PB) + (gg / NTN) * 32;
-                ahi[g % ARING] = *reinterpret_cast<const u32x4 *>(p);
-                alo[g % ARING] = *reinterpret_cast<const u32x4 *>(p + SP_LO);
+        for (int ks = 0; ks < 8; ++ks) {
+            {                                                    // weights BRING-1 k-steps ahead
+                int nxt = step0 + ks + BRING - 1;
+                nxt = nxt < 128 ? nxt : 127;
+                bh[(ks + BRING - 1) & (BRING - 1)] = wlh[nxt * 256];
+                bl[(ks + BRING - 1) & (BRING - 1)] = wll[nxt * 256];
             }
-            __builtin_amdgcn_sched_barrier(0);                   // keep the MFMA / LDS-read interleave as written
+            const half8 wh = as_half8(bh[ks & (BRING - 1)]), wl = as_half8(bl[ks & (BRING - 1)]);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int f = ks * NT + i, g = f + ARING;
+                const half8 xh = as_half8(ahi[f % ARING]), xl = as_half8(alo[f % ARING]);
+                acc[T0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, acc[T0 + i], 0, 0, 0);
+                acc[T0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, acc[T0 + i], 0, 0, 0);
+                acc[T0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, acc[T0 + i], 0, 0, 0);
+                if (g < STEPS) {
+                    const unsigned char *p = pv + (T0 + g % NT) * (W2 * PB) + (g / NT) * 32;
+                    ahi[g % ARING] = *reinterpret_cast<const u32x4 *>(p);
+                    alo[g % ARING] = *reinterpret_cast<const u32x4 *>(p + SP_LO);
+                } else if (more) {                               // first fragments of the next tap
+                    const int gg = g - STEPS;
+                    const unsigned char *p = pv + PB + (T0 + gg % NT) * (W2 * PB) + (gg / NT) * 32;
+                    ahi[g % ARING] = *reinterpret_cast<const u32x4 *>(p);
+                    alo[g % ARING] = *reinterpret_cast<const u32x4 *>(p + SP_LO);
+                }
+                __builtin_amdgcn_sched_barrier(0);               // keep the MFMA / LDS-read interleave as written
+            }
         }
     }
 }
 
-// Epilogue pieces for lane half H (compile time, so every cell index below is a constant expression).
+// Epilogue pieces.  A lane holds one output channel of 16 cells per row tile; which cells depends on the
+// lane half h only, so every per-cell constant is a select between two compile-time values.
 // Step 1: v = ReLU(acc * k[board] + bias) in place, and this lane's maximum per board.
-template <int IH, int IW, int NB, int H>
+template <int IH, int IW, int NB>
 __device__ __forceinline__ void conv_split_finish(f32x16 (&acc)[IH + 1], const float (&kin)[NB], float bv,
-                                                  float (&bmax)[NB]) {
+                                                  float (&bmax)[NB], int h) {
     constexpr int OH = IH + 1, OW = IW + 1, RC = NB * OW;
-    static_for<OH>([&](auto T) __attribute__((always_inline)) {
-        static_for<16>([&](auto Rr) __attribute__((always_inline)) {
-            constexpr int t = decltype(T)::value, r = decltype(Rr)::value;
-            constexpr int c = sigma((r & 3) + 8 * (r >> 2) + 4 * H);
-            if constexpr (c < RC) {
-                const float v = fmaxf(__builtin_fmaf(acc[t][r], kin[c / OW], bv), 0.f);
-                acc[t][r] = v;
-                bmax[c / OW] = fmaxf(bmax[c / OW], v);
-            }
+    static_for<16>([&](auto Rr) __attribute__((always_inline)) {
+        constexpr int r = decltype(Rr)::value;
+        constexpr int c0 = sigma((r & 3) + 8 * (r >> 2)), c1 = sigma((r & 3) + 8 * (r >> 2) + 4);
+        constexpr int j0 = c0 < RC ? c0 / OW : NB - 1, j1 = c1 < RC ? c1 / OW : NB - 1;
+        const bool live = h ? c1 < RC : c0 < RC;
+        const float k = h ? kin[j1] : kin[j0];
+        float mx = 0.f;
+        static_for<OH>([&](auto T) __attribute__((always_inline)) {
+            constexpr int t = decltype(T)::value;
+            const float v = fmaxf(__builtin_fmaf(acc[t][r], k, bv), 0.f);
+            acc[t][r] = v;
+            mx = fmaxf(mx, v);
+        });
+        mx = live ? mx : 0.f;
+        static_for<NB>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            if constexpr (j == j0 || j == j1) bmax[j] = fmaxf(bmax[j], (h ? j1 : j0) == j ? mx : 0.f);
         });
     });
 }
 
-// Step 2: quantise with the board's scale and put hi / lo into the output tile in LDS.
-template <int IH, int IW, int NB, int H>
+// Step 2: quantise with the board's scale and put hi / lo into the output tile in LDS.  A lane swaps its
+// (hi, lo) pair with the neighbouring channel's lane (same cell) so that the even lane stores both hi
+// halves and the odd lane both lo halves as one 32-bit word each.
+template <int IH, int IW, int NB>
 __device__ __forceinline__ void conv_split_store(const f32x16 (&acc)[IH + 1], const float (&sout)[NB],
-                                                 _Float16 *ldsh, int ch) {
+                                                 unsigned *ldsw, int ch, int odd, int h) {
     constexpr int OH = IH + 1, OW = IW + 1, OP = OH * OW, RC = NB * OW;
-    static_for<OH>([&](auto T) __attribute__((always_inline)) {
-        static_for<16>([&](auto Rr) __attribute__((always_inline)) {
-            constexpr int t = decltype(T)::value, r = decltype(Rr)::value;
-            constexpr int c = sigma((r & 3) + 8 * (r >> 2) + 4 * H);
-            if constexpr (c < RC) {
-                constexpr int R = (c / OW) * OP + t * OW + c % OW;
-                _Float16 hi, lo;
-                split_half(acc[t][r] * sout[c / OW], hi, lo);
-                ldsh[R * (SP_PB / 2) + ch] = hi;
-                ldsh[R * (SP_PB / 2) + 128 + ch] = lo;
-            }
-        });
+    const int col = (ch >> 1) + (odd ? SP_LO / 4 : 0);           // dword inside a position
+    const unsigned psel = odd ? 0x03020706u : 0x05040100u;       // v_perm_b32 byte selector, bytes 4-7 = first operand
+    static_for<16>([&](auto Rr) __attribute__((always_inline)) {
+        constexpr int r = decltype(Rr)::value;
+        constexpr int c0 = sigma((r & 3) + 8 * (r >> 2)), c1 = sigma((r & 3) + 8 * (r >> 2) + 4);
+        constexpr int j0 = c0 < RC ? c0 / OW : NB - 1, j1 = c1 < RC ? c1 / OW : NB - 1;
+        constexpr int R0 = j0 * OP + c0 % OW, R1 = j1 * OP + c1 % OW;      // tile position of output row 0
+        const bool live = h ? c1 < RC : c0 < RC;
+        const float sc_out = h ? sout[j1] : sout[j0];
+        unsigned *dst = ldsw + (h ? R1 : R0) * (SP_PB / 4) + col;
+        if (live) {
+            static_for<OH>([&](auto T) __attribute__((always_inline)) {
+                constexpr int t = decltype(T)::value;
+                typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+                half2v pr;
+                const float x = acc[t][r] * sc_out;
+                pr[0] = (_Float16)x;
+                pr[1] = (_Float16)(x - (float)pr[0]);
+                const unsigned own = __builtin_bit_cast(unsigned, pr);
+                const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);   // lane ^ 1
+                // even lane: (own hi, other hi); odd lane: (other lo, own lo)
+                dst[t * OW * (SP_PB / 4)] = __builtin_amdgcn_perm(other, own, psel);
+            });
+        }
     });
 }
+
+#ifdef NNB_SPLIT_BENCH_CLOCKS
+// timing harness only (tools/split_bench.hip): shader-clock stamps of one block's phases
+__device__ unsigned long long g_sp_clk[8];
+#define NNB_SP_STAMP(i) if (blockIdx.x == 300 && threadIdx.x == 0) g_sp_clk[i] = __builtin_readcyclecounter();
+#define NNB_SP_WALL(i) if (blockIdx.x == 300 && threadIdx.x == 0) g_sp_clk[i] = wall_clock64();
+#else
+#define NNB_SP_STAMP(i)
+#define NNB_SP_WALL(i)
+#endif
 
 constexpr size_t conv_split_lds_bytes(int ih, int iw, int nb) {
     int npos = 2 + nb * conv_board_stride(ih, iw) + 2, m = nb * (ih + 1) * (iw + 1);
@@ -244,6 +290,7 @@ __global__ __launch_bounds__(256, 1) void conv_rows_split_kernel(const u32x4 *__
     const int tid = threadIdx.x;
     const int lane = tid & 63, nt = tid >> 6, m = lane & 31, h = lane >> 5;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    NNB_SP_STAMP(0) NNB_SP_WALL(5)
 
     float kin[NB];                                               // 1 / (input scale * weight scale) per board
     if constexpr (FUSE_IN) {
@@ -301,13 +348,40 @@ __global__ __launch_bounds__(256, 1) void conv_rows_split_kernel(const u32x4 *__
         const float k = sc->inv_sa1 * sc->inv_sw2;
         static_for<NB>([&](auto J) __attribute__((always_inline)) { kin[decltype(J)::value] = k; });
     } else {
-        // one pass over the image: input pixels from memory, zeros everywhere else
+        // input pixels from memory in batches of SB loads per thread (one wave per SIMD: nothing else hides
+        // the latency of a load that is waited for at once), zeros into every position that holds no pixel
         const u32x4 *src = in + (size_t)b0i * IP * 32;
-        for (int e = tid; e < NPOS * 32; e += 256) {
+        constexpr int NDATA = NB * IP * 32, SB = 9, NBATCH = (NDATA + 256 * SB - 1) / (256 * SB);
+        const int ndata = nb_valid * IP * 32;
+        auto image_chunk = [&](int e) __attribute__((always_inline)) {      // data chunk e -> chunk index in the image
+            const int pix = e >> 5, q = e & 31, j = pix / IP, p = pix - j * IP;
+            return (LEAD + j * BS + (p / IW) * W2 + p % IW) * SP_RS + q;
+        };
+        u32x4 sv[SB];
+        static_for<SB>([&](auto K) __attribute__((always_inline)) {
+            constexpr int k = decltype(K)::value;
+            const int e = tid + 256 * k;
+            sv[k] = e < ndata ? src[e] : zero4;
+        });
+        for (int e = tid; e < NPOS * 32; e += 256) {             // zero positions, while the first batch is in flight
             const int pos = e >> 5, q = e & 31;
             const int rel = pos - LEAD, j = rel / BS, rem = rel - j * BS, ih = rem / W2, iw = rem - ih * W2;
-            const bool data = rel >= 0 && j < nb_valid && ih < IH && iw < IW;
-            lds[pos * SP_RS + q] = data ? src[((j * IH + ih) * IW + iw) * 32 + q] : zero4;
+            const bool data = rel >= 0 && j < NB && ih < IH && iw < IW;
+            if (!data) lds[pos * SP_RS + q] = zero4;
+        }
+#pragma unroll 1
+        for (int bt = 0; bt < NBATCH; ++bt) {
+            static_for<SB>([&](auto K) __attribute__((always_inline)) {
+                constexpr int k = decltype(K)::value;
+                const int e = tid + 256 * (bt * SB + k);
+                if (e < NDATA) lds[image_chunk(e)] = sv[k];
+            });
+            if (bt + 1 < NBATCH)
+                static_for<SB>([&](auto K) __attribute__((always_inline)) {
+                    constexpr int k = decltype(K)::value;
+                    const int e = tid + 256 * ((bt + 1) * SB + k);
+                    sv[k] = e < ndata ? src[e] : zero4;
+                });
         }
         const float inv_sw = sc->inv_sw4;
         static_for<NB>([&](auto J) __attribute__((always_inline)) {
@@ -316,6 +390,7 @@ __global__ __launch_bounds__(256, 1) void conv_rows_split_kernel(const u32x4 *__
         });
     }
     __syncthreads();
+    NNB_SP_STAMP(1)
 
     // this lane's cell of every output row: board j, column ow (lanes past the last cell repeat it)
     int cell = sigma(m);
@@ -333,33 +408,18 @@ __global__ __launch_bounds__(256, 1) void conv_rows_split_kernel(const u32x4 *__
     u32x4 bh[BRING], bl[BRING];
 #pragma unroll
     for (int i = 0; i < BRING - 1; ++i) { bh[i] = wlh[i * 256]; bl[i] = wll[i * 256]; }
-    u32x4 ahi[ARING], alo[ARING];
-    {
-        constexpr int T0 = rows_t0(0), NT0 = rows_t1(IH, 0) - T0;
-        const int vb = lane_base + (-2 * W2 - 2) * PB;
-#pragma unroll
-        for (int f = 0; f < ARING; ++f) {
-            const unsigned char *p = smem_raw + vb + (T0 + f % NT0) * (W2 * PB) + (f / NT0) * 32;
-            ahi[f] = *reinterpret_cast<const u32x4 *>(p);
-            alo[f] = *reinterpret_cast<const u32x4 *>(p + SP_LO);
-        }
-    }
-#define NNB_SPLIT_KH(KH)                                                                                          \
-    {                                                                                                             \
-        _Pragma("unroll 1") for (int kw = 0; kw < 3; ++kw)                                                        \
-            conv_split_body<IH, IW, ARING, BRING, KH, false>(acc, ahi, alo, bh, bl, smem_raw, lane_base, kw, wlh, wll); \
-        conv_split_body<IH, IW, ARING, BRING, KH, true>(acc, ahi, alo, bh, bl, smem_raw, lane_base, 3, wlh, wll);  \
-    }
-    NNB_SPLIT_KH(0) NNB_SPLIT_KH(1) NNB_SPLIT_KH(2) NNB_SPLIT_KH(3)
-#undef NNB_SPLIT_KH
+    conv_split_row<IH, IW, ARING, BRING, 0>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
+    conv_split_row<IH, IW, ARING, BRING, 1>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
+    conv_split_row<IH, IW, ARING, BRING, 2>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
+    conv_split_row<IH, IW, ARING, BRING, 3>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
 
+    NNB_SP_STAMP(2)
     // epilogue: bias + ReLU in float32, each board's maximum over the whole block, then hi / lo with
     // that board's scale into the output tile [board][cell][hi 128 | lo 128] in LDS, then row-contiguous stores
     const float bv = bias[nt * 32 + m];
     float bmax[NB];
     static_for<NB>([&](auto J) __attribute__((always_inline)) { bmax[decltype(J)::value] = 0.f; });
-    if (h == 0) conv_split_finish<IH, IW, NB, 0>(acc, kin, bv, bmax);
-    else conv_split_finish<IH, IW, NB, 1>(acc, kin, bv, bmax);
+    conv_split_finish<IH, IW, NB>(acc, kin, bv, bmax, h);
     static_for<NB>([&](auto J) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value;
         float v = bmax[j];
@@ -368,6 +428,7 @@ __global__ __launch_bounds__(256, 1) void conv_rows_split_kernel(const u32x4 *__
         if (lane == 0) s_max[nt * NB + j] = v;
     });
     __syncthreads();                                             // every wave is done with the image
+    NNB_SP_STAMP(4)
     float sout[NB], sinv[NB];
     static_for<NB>([&](auto J) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value;
@@ -375,20 +436,34 @@ __global__ __launch_bounds__(256, 1) void conv_rows_split_kernel(const u32x4 *__
         sout[j] = pow2_scale(mx, sinv[j]);
     });
     {
-        _Float16 *ldsh = reinterpret_cast<_Float16 *>(smem_raw);
-        if (h == 0) conv_split_store<IH, IW, NB, 0>(acc, sout, ldsh, nt * 32 + m);
-        else conv_split_store<IH, IW, NB, 1>(acc, sout, ldsh, nt * 32 + m);
+        unsigned *ldsw = reinterpret_cast<unsigned *>(smem_raw);
+        conv_split_store<IH, IW, NB>(acc, sout, ldsw, nt * 32 + m, m & 1, h);
     }
     __syncthreads();
+    NNB_SP_STAMP(7)
     u32x4 *dst = out + (size_t)b0i * OP * 32;
     const int nchunks = nb_valid * OP * 32;
-    for (int e = tid; e < nchunks; e += 256) dst[e] = lds[(e >> 5) * SP_RS + (e & 31)];
+    constexpr int CB = 8;                                        // LDS reads in flight per thread
+    for (int e0 = tid; e0 < nchunks; e0 += 256 * CB) {
+        u32x4 cv[CB];
+        static_for<CB>([&](auto K) __attribute__((always_inline)) {
+            constexpr int k = decltype(K)::value;
+            const int e = min(e0 + 256 * k, nchunks - 1);
+            cv[k] = lds[(e >> 5) * SP_RS + (e & 31)];
+        });
+        static_for<CB>([&](auto K) __attribute__((always_inline)) {
+            constexpr int k = decltype(K)::value;
+            const int e = e0 + 256 * k;
+            if (e < nchunks) dst[e] = cv[k];
+        });
+    }
     float my_inv = sinv[0];                                      // selects, not an indexed read of the array
     static_for<NB>([&](auto J) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value;
         my_inv = tid == j ? sinv[j] : my_inv;
     });
     if (tid < nb_valid) out_inv_scale[b0i + tid] = my_inv;
+    NNB_SP_STAMP(3) NNB_SP_WALL(6)
 }
 
 // ---------------------------------------------------------------------------

@@ -41,6 +41,8 @@ int fail(int code, const char *fmt, ...) {
 constexpr size_t kAlign = 256;
 constexpr int kMaxSims = 9000;           // first_child is 16 bit: 1 + 7*sims <= 65535
 constexpr size_t kFusedLdsLimit = 160 * 1024;   // LDS of one CU
+constexpr int kHalvesMinSlots = 1024;    // below this a round is not split over two streams
+constexpr int kStepGamesHost = 16;       // games per block of the tree step kernel (halves are cut on a block boundary)
 constexpr int kProfClasses = 7;
 constexpr int kProfSamples = 16;         // event pairs per class per drain
 
@@ -136,12 +138,12 @@ size_t carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std:
         b.fc = c.take<float>(G * 1024);
         b.fc_b1 = c.take<float>(G * 1024);
         b.fcpart = b.fcpart_b1 = nullptr;
-        const bool two = cfg.n_weight_sets > 1;          // second batch only exists with two networks
+        const bool two = true;     // the second leaf batch: the other network of an arena, or the other half of the slots
         b.act1_b1 = two ? c.take<float>(G * 56 * 128) : nullptr;
         b.act2_b1 = two ? c.take<float>(G * 72 * 128) : nullptr;
         b.act3_b1 = two ? c.take<float>(G * 90 * 128) : nullptr;
     } else if (cfg.net_precision == NNB_NET_F32S) {      // hi + lo halves: 4 bytes per value, plus a scale per board
-        const bool two = cfg.n_weight_sets > 1;
+        const bool two = true;
         b.act1 = b.act1_b1 = nullptr;
         b.fc = b.fc_b1 = nullptr;
         b.act2 = c.take<float>(G * 72 * 128);
@@ -161,7 +163,7 @@ size_t carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std:
         b.fc = b.fc_b1 = nullptr;
         b.fcpart = c.take<float>(2 * G * 1024);
         b.fcpart_b1 = c.take<float>(2 * G * 1024);
-        const bool two = cfg.n_weight_sets > 1;
+        const bool two = true;
         b.act1_b1 = nullptr;
         b.act2_b1 = two ? reinterpret_cast<float *>(c.take<uint16_t>(G * 72 * 128)) : nullptr;
         b.act3_b1 = two ? reinterpret_cast<float *>(c.take<uint16_t>(G * 90 * 128)) : nullptr;
@@ -554,7 +556,7 @@ int nnb_engine_create(const nnb_config *cfg, void *workspace, size_t workspace_b
     HIP_TRY(hipMemcpyAsync(e->dev.log_table, logt.data(), logt.size() * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->host_counters), 64 * sizeof(int32_t), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->host_stats), 32 * sizeof(unsigned long long), hipHostMallocDefault));
-    if (cfg->n_weight_sets > 1) {
+    {
         HIP_TRY(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&e->fork_event, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->join_event, hipEventDisableTiming));
@@ -765,13 +767,51 @@ int nnb_selfplay_round(nnb_engine *e, void *stream, const nnb_search_params *par
             if (!(sd.dirichlet_alpha > 0.0)) return fail(NNB_ERR_ARG, "dirichlet_eps > 0 needs dirichlet_alpha > 0");
             make_noise = 1;
         }
-        const StepPlan plan = make_step_plan(e, *params, sd);
+        StepPlan plan = make_step_plan(e, *params, sd);
         constexpr int kChunk = 64;
         e->prof_stride = kChunk / kProfSamples + 1;
         launch_tree_init(st, e->dev, sd, make_noise, 1);
         long long max_steps = ((long long)n_games / (slots > 0 ? slots : 1) + 2) * (kMaxPlies + 1) * (params->sims + 1);
         if (params->round_limit > 0 && params->round_limit < max_steps) max_steps = params->round_limit;
-        while (live > 0 && steps < max_steps) {
+        // One network and enough slots: the slots are split in two halves, each with a leaf batch, activation
+        // buffers and a stream of its own, and each half runs its own tree step -> forward pass chain.  The two
+        // chains are not synchronised with each other, so one half's tree step runs under the other half's forward
+        // pass, and the CUs that the last blocks of one kernel leave idle take blocks of the other half's kernels.
+        // Games do not interact, so the records are the same byte for byte.
+        // Measured on 4096 slots x 200 simulations: +5 % games/s with the float32-faithful kernels (one block per CU,
+        // long tails), -3 % with the half-input kernels (two blocks per CU already overlap), so those keep one chain.
+        const bool wanted = (params->flags & NNB_FLAG_TWO_STREAMS) ||
+                            (slots >= kHalvesMinSlots && e->cfg.net_precision != NNB_NET_F16);
+        const bool halves = plan.nbatch == 1 && slots >= 2 * kStepGamesHost && wanted && !(params->flags & NNB_FLAG_ONE_STREAM);
+        if (halves) {
+            const int mid = (slots / 2 + kStepGamesHost - 1) / kStepGamesHost * kStepGamesHost;
+            const GameSpan span[2] = {{0, mid, 0}, {mid, slots, 1}};
+            if (plan.heads.fused) plan.heads.h[1] = heads_input(e, sd.wset[0], 1);
+            hipStream_t hs[2] = {st, e->side_stream};
+            while (live > 0 && steps < max_steps) {
+                (void)hipEventRecord(e->fork_event, st);
+                (void)hipStreamWaitEvent(e->side_stream, e->fork_event, 0);
+                for (int k = 0; k < kChunk; ++k, ++steps) {
+                    const int parity = (int)(steps & 1);
+                    for (int b = 0; b < 2; ++b) {
+                        if (make_noise) launch_turnover(hs[b], e->dev, sd, round, make_noise, &span[b]);
+                        { ProfScope ps(e, 0, hs[b]); launch_tree_step(hs[b], e->dev, sd, parity, plan.heads, make_noise ? nullptr : &round, &span[b]); }
+                        if (params->evaluator == NNB_EVAL_NET)
+                            forward_leaves(e, hs[b], sd.wset[0], b, parity, span[b].end - span[b].first, !plan.heads.fused);
+                        else
+                            launch_fixed_eval(hs[b], e->dev, sd, b, parity);
+                    }
+                }
+                (void)hipEventRecord(e->join_event, e->side_stream);
+                (void)hipStreamWaitEvent(st, e->join_event, 0);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(e->host_counters, e->dev.counters + kLive, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                prof_drain(e);
+                live = e->host_counters[0];
+            }
+        }
+        while (!halves && live > 0 && steps < max_steps) {
             for (int k = 0; k < kChunk; ++k, ++steps) {
                 // with root noise to draw the turnover is a launch of its own, otherwise part of the step
                 if (make_noise) launch_turnover(st, e->dev, sd, round, make_noise);

@@ -435,15 +435,19 @@ __device__ void readout_game(const EngineDev &e, const SearchDev &p, int g, int3
 // CACHE (NNB_FLAG_EVAL_CACHE): the evaluation of every leaf is filed in the game's direct-mapped
 // table when it arrives; a leaf whose position is already there ends its simulation on the spot
 // with the filed value and priors, exactly as the fresh evaluation would have a round later.
+//
+// SPAN: the launch covers games [span.first, span.end) only and files its leaves in batch span.batch
+// (-1: batch by root mover's weight set, as above).  Two launches over the two halves of the slots, each
+// with a batch and a stream of its own, let one half's tree step run under the other half's forward pass.
 template <bool AZ, bool HEADS, bool TURNOVER, bool CACHE>
 __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e, SearchDev p, int parity, HeadsPair hp,
-                                                                    RoundDev round) {
+                                                                    RoundDev round, GameSpan span) {
     __shared__ int s_want[kStepGames];       // 0 = no leaf, 1 + batch otherwise
     __shared__ int s_base[2];
     extern __shared__ __attribute__((aligned(16))) float4 s_hw[];      // [batches][HROWS][256]
     constexpr int HROWS = AZ ? 8 : 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int g = blockIdx.x * kStepGames + wv;
+    const int g = span.first + blockIdx.x * kStepGames + wv;
     if constexpr (HEADS) {
         const int nb = p.wset[0] != p.wset[1] ? 2 : 1;
         for (int i = threadIdx.x; i < nb * HROWS * 256; i += kStepGames * 64) {
@@ -452,8 +456,11 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
         }
         __syncthreads();
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { e.leaf_count[2 * (parity ^ 1)] = 0; e.leaf_count[2 * (parity ^ 1) + 1] = 0; }
-    bool live = g < e.n_games && e.active[g];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {               // the next step's batch sizes start at zero
+        if (span.batch < 0) { e.leaf_count[2 * (parity ^ 1)] = 0; e.leaf_count[2 * (parity ^ 1) + 1] = 0; }
+        else e.leaf_count[2 * (parity ^ 1) + span.batch] = 0;
+    }
+    bool live = g < span.end && e.active[g];
     if constexpr (TURNOVER) {
         if (live && e.pending[g] < 0 && e.sims_done[g] >= p.sims) {
             if (lane == 0) {
@@ -480,7 +487,8 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
     n_nodes = e.n_nodes[g];
     const int player = e.root_player[g];
     const u64 r1 = e.root_boards[2 * g], r2 = e.root_boards[2 * g + 1];
-    batch = two_batches ? player - 1 : 0;      // every leaf of a search is judged by the root mover's network
+    // every leaf of a search is judged by the root mover's network; with one network, by the launch's batch
+    batch = two_batches ? player - 1 : (span.batch < 0 ? 0 : span.batch);
     CacheEntry *table = nullptr;
     uint32_t gen = 0;
     if constexpr (CACHE) { table = e.cache + (size_t)g * e.cache_slots; gen = e.cache_gen[g]; }
@@ -498,7 +506,7 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
             const HeadsDev &hd = hp.h[b];
             float4 xv[4];
             heads_load_row(hd, (size_t)(pend - b * e.max_games), lane, xv);
-            const float4 *hw = s_hw + b * HROWS * 256;
+            const float4 *hw = s_hw + (two_batches ? b : 0) * HROWS * 256;
             if constexpr (AZ) {
                 float z[8], lp[7], pri[7];
 #pragma unroll
@@ -821,9 +829,9 @@ __global__ void readout_kernel(EngineDev e, SearchDev p, int32_t *__restrict__ v
 // of exactly those games whose simulation budget is used up (root readout, move, trajectory,
 // retirement or the next game of the round) and starts their next search.  Games that search
 // long positions no longer hold back games that are done, so the leaf batch stays full.
-__global__ void turnover_kernel(EngineDev e, SearchDev p, RoundDev round, int make_noise) {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= e.n_games) return;
+__global__ void turnover_kernel(EngineDev e, SearchDev p, RoundDev round, int make_noise, GameSpan span) {
+    int g = span.first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= span.end) return;
     if (!e.active[g]) return;
     if (e.pending[g] >= 0 || e.sims_done[g] < p.sims) return;
     readout_game(e, p, g, nullptr, nullptr, nullptr, round, 1);
@@ -887,7 +895,7 @@ __global__ void stats_reduce_kernel(EngineDev e) {
 
 // Fixed evaluators over the compacted leaf batch: fills the value buffer exactly as the
 // network's heads kernel would, so the lock-step path can be run without weights.
-__global__ void fixed_eval_kernel(EngineDev e, SearchDev p, int batch, int parity) {
+__global__ void fixed_eval_kernel(EngineDev e, SearchDev p, int batch, int parity) {   // one launch per batch
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= e.leaf_count[2 * parity + batch]) return;
     i += batch * e.max_games;
@@ -1060,30 +1068,32 @@ void launch_tree_init(hipStream_t st, const EngineDev &e, const SearchDev &p, in
 
 template <bool AZ, bool HEADS>
 static void launch_tree_step_t(hipStream_t st, const EngineDev &e, const SearchDev &p, int parity, const HeadsPair &heads,
-                               const RoundDev *turnover, size_t lds) {
-    const int blocks = cdiv(e.n_games, kStepGames), threads = kStepGames * 64;
+                               const RoundDev *turnover, size_t lds, const GameSpan &span) {
+    const int blocks = cdiv(span.end - span.first, kStepGames), threads = kStepGames * 64;
+    if (blocks <= 0) return;
     const RoundDev none = {nullptr, nullptr, nullptr, 0, 0};
     const bool cache = (p.flags & NNB_FLAG_EVAL_CACHE) && e.cache;
     if (turnover) {
-        if (cache) tree_step_kernel<AZ, HEADS, true, true><<<blocks, threads, lds, st>>>(e, p, parity, heads, *turnover);
-        else tree_step_kernel<AZ, HEADS, true, false><<<blocks, threads, lds, st>>>(e, p, parity, heads, *turnover);
+        if (cache) tree_step_kernel<AZ, HEADS, true, true><<<blocks, threads, lds, st>>>(e, p, parity, heads, *turnover, span);
+        else tree_step_kernel<AZ, HEADS, true, false><<<blocks, threads, lds, st>>>(e, p, parity, heads, *turnover, span);
     } else {
-        if (cache) tree_step_kernel<AZ, HEADS, false, true><<<blocks, threads, lds, st>>>(e, p, parity, heads, none);
-        else tree_step_kernel<AZ, HEADS, false, false><<<blocks, threads, lds, st>>>(e, p, parity, heads, none);
+        if (cache) tree_step_kernel<AZ, HEADS, false, true><<<blocks, threads, lds, st>>>(e, p, parity, heads, none, span);
+        else tree_step_kernel<AZ, HEADS, false, false><<<blocks, threads, lds, st>>>(e, p, parity, heads, none, span);
     }
 }
 
 // turnover != null: games whose budget is used up end their move inside the step (see TURNOVER)
 void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, int parity, const HeadsPair &heads,
-                      const RoundDev *turnover) {
+                      const RoundDev *turnover, const GameSpan *span_or_null) {
     const bool az = p.mode == NNB_MODE_AZ;
+    const GameSpan span = span_or_null ? *span_or_null : GameSpan{0, e.n_games, -1};
     if (heads.fused) {
         const size_t lds = (size_t)(p.wset[0] != p.wset[1] ? 2 : 1) * (az ? 8 : 1) * 4096;
-        if (az) launch_tree_step_t<true, true>(st, e, p, parity, heads, turnover, lds);
-        else launch_tree_step_t<false, true>(st, e, p, parity, heads, turnover, lds);
+        if (az) launch_tree_step_t<true, true>(st, e, p, parity, heads, turnover, lds, span);
+        else launch_tree_step_t<false, true>(st, e, p, parity, heads, turnover, lds, span);
     } else {
-        if (az) launch_tree_step_t<true, false>(st, e, p, parity, heads, turnover, 0);
-        else launch_tree_step_t<false, false>(st, e, p, parity, heads, turnover, 0);
+        if (az) launch_tree_step_t<true, false>(st, e, p, parity, heads, turnover, 0, span);
+        else launch_tree_step_t<false, false>(st, e, p, parity, heads, turnover, 0, span);
     }
 }
 
@@ -1126,8 +1136,11 @@ void launch_readout(hipStream_t st, const EngineDev &e, const SearchDev &p, int3
                                                          round ? *round : none, round != nullptr);
 }
 
-void launch_turnover(hipStream_t st, const EngineDev &e, const SearchDev &p, const RoundDev &round, int make_noise) {
-    turnover_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, p, round, make_noise);
+void launch_turnover(hipStream_t st, const EngineDev &e, const SearchDev &p, const RoundDev &round, int make_noise,
+                     const GameSpan *span_or_null) {
+    const GameSpan span = span_or_null ? *span_or_null : GameSpan{0, e.n_games, -1};
+    if (span.end <= span.first) return;
+    turnover_kernel<<<cdiv(span.end - span.first, 256), 256, 0, st>>>(e, p, round, make_noise, span);
 }
 
 void launch_minimax(hipStream_t st, int n, const u64 *boards, const int8_t *movers, int depth, int8_t *col_out,

@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--no-eval-cache-line", action="store_true",
                     help="skip the extra, untimed round with the per-game evaluation cache (reported apart from `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="keep all games in one tree step -> forward pass chain instead of two halves on two streams")
     args = ap.parse_args()
 
     import torch
@@ -138,7 +140,7 @@ def main():
     engine = Engine(max_games=G, max_sims=args.sims, device=device, precision=args.precision,
                     eval_cache_slots=2048 if cache_line else 0)
     engine.load_state_dict(seeded_state_dict(0))
-    params = engine.params(args.sims, C_PUCT, evaluator="net", mode="compat")
+    params = engine.params(args.sims, C_PUCT, evaluator="net", mode="compat", one_stream=args.one_stream)
     traj = torch.empty((G, TRAJECTORY_BYTES), dtype=torch.uint8, device=device)
     replay = torch.empty((world * G, TRAJECTORY_BYTES), dtype=torch.uint8, device=device) if use_dist else traj
 

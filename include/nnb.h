@@ -87,7 +87,14 @@ enum nnb_flags {
      * the position, so the games are the same byte for byte; only the number of leaves sent to
      * the network drops.  Off by default (the reference evaluates every leaf, agent_code.py:195);
      * needs an engine created with eval_cache_slots > 0. */
-    NNB_FLAG_EVAL_CACHE = 8
+    NNB_FLAG_EVAL_CACHE = 8,
+    /* nnb_selfplay_round on the lock-step path with one network.  The slots can be split in two halves
+     * that run their tree step -> forward pass chains on two streams, unsynchronised, so that one half's
+     * tree step and the idle tail of its kernels hide under the other half's forward pass.  Same games
+     * either way.  Default: two streams from 1024 slots on with NNB_NET_F32S / NNB_NET_F32, one stream with
+     * NNB_NET_F16 (where it measured slower).  ONE_STREAM / TWO_STREAMS force the choice. */
+    NNB_FLAG_ONE_STREAM = 16,
+    NNB_FLAG_TWO_STREAMS = 32
 };
 
 /* How the network's three big layers multiply.  All accumulate in float32 and keep bias,

@@ -181,3 +181,42 @@ def test_random_openings_are_legal_positions(gpu, oracle):
                 assert len({(int(a), int(b)) for a, b in boards}) > 20
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("mode,evaluator,precision", [("compat", "hash_f32", "f16"), ("az", "hash_q8", "f16"),
+                                                      ("compat", "net", "f32s"), ("az", "net", "f16")])
+def test_two_halves_on_two_streams_play_the_same_games(gpu, oracle, mode, evaluator, precision):
+    """A round with at least 1024 slots runs as two halves on two unsynchronised streams (one half's tree step
+    under the other half's forward pass); one_stream keeps the single chain.  Same records byte for byte,
+    with refill (more games than slots) and with games of very different lengths."""
+    from alphazero_amd.engine import Engine, trajectories_to_numpy
+    co, rp = oracle
+    slots, n, sims = 1100, 1500, 24
+    pos = _positions(co, n, seed=11, max_plies=34)
+    boards = np.array([(p[0], p[1]) for p in pos], dtype=np.uint64)
+    players = np.array([p[2] for p in pos], dtype=np.int8)
+    eng = Engine(max_games=slots, max_sims=sims, precision=precision)
+    try:
+        if evaluator == "net":
+            eng.load_state_dict(rp.seeded_state_dict(0))
+        kw = dict(evaluator=evaluator, mode=mode, lockstep=True, seed=5)
+        if mode == "az":
+            kw.update(dirichlet_alpha=0.3, dirichlet_eps=0.25)
+        out = []
+        for one_stream in (True, False, False):
+            traj, stats = eng.selfplay_round(n, eng.params(sims, 1.4, one_stream=one_stream, two_streams=not one_stream, **kw),
+                                             first_game_id=9,
+                                             start_boards=boards, start_players=players)
+            out.append((trajectories_to_numpy(traj).copy(), stats))
+    finally:
+        eng.close()
+    assert out[0][0].tobytes() == out[1][0].tobytes() == out[2][0].tobytes()
+    for key in ("games", "plies", "sims", "net_leaves", "terminal_hits", "depth_sum"):
+        assert out[0][1][key] == out[1][1][key] == out[2][1][key], key
+    assert (out[0][0]["result"] != 2).all()
+    if evaluator != "net" and mode == "compat":        # and they are the oracle's games
+        for i in (0, 1, 549, 550, 551, 1099, 1100, 1499):
+            b1, b2, player = pos[i]
+            moves, visits, result, final, _ = co.selfplay_game(sims, 1.4, evaluator, b1, b2, player)
+            r = out[1][0][i]
+            assert r["plies"]["action"][:r["length"]].tolist() == moves and r["plies"]["visits"][:len(moves)].tolist() == visits

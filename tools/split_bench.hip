@@ -1,0 +1,107 @@
+// Timing experiments on the split-operand network kernels (not part of the product): each kernel on
+// synthetic data, timed with HIP events, with shader-clock stamps of one block's phases.
+#define NNB_SPLIT_BENCH_CLOCKS 1
+#include "../alphazero_amd/csrc/net_kernels_split.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using namespace nnb;
+namespace nnb {     // the heads stage lives in another translation unit of the library; never called here
+void launch_net_stage_f16(hipStream_t, int, const NetWeights &, const NetBuffers &, const u64 *, const uint8_t *, float *,
+                          float *, float *, const int32_t *, int) {}
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <typename T> T *dev_random_halves(size_t n_halves, float lo, float hi, unsigned seed) {
+    std::vector<_Float16> h(n_halves);
+    unsigned s = seed * 2654435761u + 1;
+    for (size_t i = 0; i < n_halves; ++i) {
+        s = s * 1664525u + 1013904223u;
+        h[i] = (_Float16)(lo + (hi - lo) * (float)(s >> 8) / 16777216.0f);
+    }
+    void *d; CK(hipMalloc(&d, n_halves * 2)); CK(hipMemcpy(d, h.data(), n_halves * 2, hipMemcpyHostToDevice));
+    return (T *)d;
+}
+
+static void report(const char *name, float us, double flop) {
+    unsigned long long h[8]; CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sp_clk), sizeof h));
+    double mhz = (h[6] > h[5]) ? (double)(h[3] - h[0]) / (double)(h[6] - h[5]) * 100.0 : 0.0;
+    printf("%-34s %8.1f us  %7.1f TFLOP/s   block: stage %6llu  main %7llu  epilogue %6llu (relu+max %llu, tile %llu, copy-out %llu) cycles  clock %.0f MHz\n", name, us,
+           flop / (us * 1e-6) / 1e12, h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[2], h[7] - h[4], h[3] - h[7], mhz);
+}
+
+int main(int argc, char **argv) {
+    const int n = argc > 1 ? atoi(argv[1]) : 3979, iters = 20;
+    u32x4 *act2 = dev_random_halves<u32x4>((size_t)n * 72 * 256, 0.f, 1.f, 1);
+    u32x4 *act3; CK(hipMalloc((void **)&act3, (size_t)n * 90 * 512));
+    u32x4 *act2o; CK(hipMalloc((void **)&act2o, (size_t)n * 72 * 512));
+    u32x4 *w2h = dev_random_halves<u32x4>(128 * 128 * 16, -1.f, 1.f, 2), *w2l = dev_random_halves<u32x4>(128 * 128 * 16, -1e-3f, 1e-3f, 3);
+    u32x4 *w0h = dev_random_halves<u32x4>(128 * 32, -1.f, 1.f, 4), *w0l = dev_random_halves<u32x4>(128 * 32, -1e-3f, 1e-3f, 5);
+    u32x4 *wfh = dev_random_halves<u32x4>((size_t)1024 * 11520, -1.f, 1.f, 6), *wfl = dev_random_halves<u32x4>((size_t)1024 * 11520, -1e-3f, 1e-3f, 7);
+    float *bias, *inv, *inv_o, *part; SplitScales *sc; unsigned long long *side;
+    CK(hipMalloc((void **)&bias, 1024 * 4)); CK(hipMemset(bias, 0, 1024 * 4));
+    CK(hipMalloc((void **)&inv, (size_t)n * 4)); CK(hipMalloc((void **)&inv_o, (size_t)n * 4));
+    CK(hipMalloc((void **)&part, (size_t)2 * n * 1024 * 4));
+    std::vector<float> ones(n, 1.0f / 16384.f); CK(hipMemcpy(inv, ones.data(), n * 4, hipMemcpyHostToDevice));
+    SplitScales hs = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f / 16384.f, 1.f, 1.f / 16384.f, 1.f, 1.f / 16384.f};
+    CK(hipMalloc((void **)&sc, sizeof hs)); CK(hipMemcpy(sc, &hs, sizeof hs, hipMemcpyHostToDevice));
+    std::vector<unsigned long long> hside(2 * n);
+    for (int i = 0; i < n; ++i) { hside[2 * i] = (0x0000040810204081ULL * (i % 7 + 1)) & 0xFDFBF7EFDFBFULL; hside[2 * i + 1] = (0x0000081020408102ULL << (i % 3)) & 0xFDFBF7EFDFBFULL & ~hside[2 * i]; }
+    CK(hipMalloc((void **)&side, 16 * n)); CK(hipMemcpy(side, hside.data(), 16 * n, hipMemcpyHostToDevice));
+    CK(prepare_net_kernels_split());
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    auto time_it = [&](auto launch) {
+        for (int i = 0; i < 3; ++i) launch();
+        CK(hipEventRecord(a, 0));
+        for (int i = 0; i < iters; ++i) launch();
+        CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); CK(hipGetLastError());
+        return ms / iters * 1000.f;
+    };
+    float us = time_it([&] {
+        conv_rows_split_kernel<7, 8, CS_NB, 4, 8, true><<<cdiv_sp(n, CS_NB), 256, C2S_SPLIT_LDS, 0>>>(
+            nullptr, nullptr, w2h, w2l, bias, sc, act2o, inv_o, nullptr, n, side, w0h, w0l, bias);
+    });
+    report("conv 7x8->8x9 (+2->128 fused)", us, (double)n * 2 * 128 * 72 * 2048);
+    us = time_it([&] {
+        conv_rows_split_kernel<8, 9, CS_NB, 4, 8, false><<<cdiv_sp(n, CS_NB), 256, C4S_SPLIT_LDS, 0>>>(
+            act2, inv, w2h, w2l, bias, sc, act3, inv_o, nullptr, n, nullptr, nullptr, nullptr, nullptr);
+    });
+    report("conv 8x9->9x10", us, (double)n * 2 * 128 * 90 * 2048);
+    {   // two half batches on two streams (conv 7x8 + conv 8x9 each) against the same work on one stream
+        hipStream_t s1, s2; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        const int nh = n / 2;
+        auto half = [&](hipStream_t st, int off, int cnt) {
+            conv_rows_split_kernel<7, 8, CS_NB, 4, 8, true><<<cdiv_sp(cnt, CS_NB), 256, C2S_SPLIT_LDS, st>>>(
+                nullptr, nullptr, w2h, w2l, bias, sc, act2o + (size_t)off * 72 * 32, inv_o + off, nullptr, cnt, side + 2 * off, w0h, w0l, bias);
+            conv_rows_split_kernel<8, 9, CS_NB, 4, 8, false><<<cdiv_sp(cnt, CS_NB), 256, C4S_SPLIT_LDS, st>>>(
+                act2 + (size_t)off * 72 * 32, inv + off, w2h, w2l, bias, sc, act3 + (size_t)off * 90 * 32, inv_o + off, nullptr, cnt, nullptr, nullptr, nullptr, nullptr);
+        };
+        hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, s1)); CK(hipStreamWaitEvent(s2, e0, 0));
+            for (int i = 0; i < iters; ++i) { half(s1, 0, nh); half(s2, nh, n - nh); }
+            CK(hipEventRecord(e2, s2)); CK(hipStreamWaitEvent(s1, e2, 0)); CK(hipEventRecord(e1, s1));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) printf("two convs, half batches on two streams: %8.1f us per full batch\n", ms / iters * 1000.f);
+        }
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, s1));
+            for (int i = 0; i < iters; ++i) half(s1, 0, n);
+            CK(hipEventRecord(e1, s1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) printf("two convs, full batch on one stream:    %8.1f us per full batch\n", ms / iters * 1000.f);
+        }
+    }
+    u32x4 *a3 = dev_random_halves<u32x4>((size_t)n * 90 * 256, 0.f, 1.f, 8);
+    us = time_it([&] {
+        int groups = cdiv_sp(cdiv_sp(n, 128), 32);
+        fc_split_kernel<<<256 * groups, 256, 0, 0>>>(a3, inv, wfh, wfl, sc, part, nullptr, n, n);
+    });
+    printf("%-34s %8.1f us  %7.1f TFLOP/s\n", "linear 11520->1024", us, (double)n * 2 * 11520 * 1024 / (us * 1e-6) / 1e12);
+    return 0;
+}
