@@ -25,7 +25,7 @@ from .network import Connect4Net
 logger = logging.getLogger(__name__)
 
 MODEL_PATH = "nnbattle/agents/alphazero/model/alphazero_model_final.pth"   # utils.py:31
-DEFAULT_PRECISION = "f32"
+DEFAULT_PRECISION = "f32s"
 
 
 class Agent(ABC):

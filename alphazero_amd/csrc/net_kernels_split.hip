@@ -246,8 +246,9 @@ __device__ __forceinline__ void conv_split_store(const f32x16 (&acc)[IH + 1], co
 #ifdef NNB_SPLIT_BENCH_CLOCKS
 // timing harness only (tools/split_bench.hip): shader-clock stamps of one block's phases
 __device__ unsigned long long g_sp_clk[8];
-#define NNB_SP_STAMP(i) if (blockIdx.x == 300 && threadIdx.x == 0) g_sp_clk[i] = __builtin_readcyclecounter();
-#define NNB_SP_WALL(i) if (blockIdx.x == 300 && threadIdx.x == 0) g_sp_clk[i] = wall_clock64();
+#define NNB_SP_BLOCK 100
+#define NNB_SP_STAMP(i) if (blockIdx.x == NNB_SP_BLOCK && threadIdx.x == 0) g_sp_clk[i] = __builtin_readcyclecounter();
+#define NNB_SP_WALL(i) if (blockIdx.x == NNB_SP_BLOCK && threadIdx.x == 0) g_sp_clk[i] = wall_clock64();
 #else
 #define NNB_SP_STAMP(i)
 #define NNB_SP_WALL(i)
@@ -478,13 +479,21 @@ __global__ __launch_bounds__(256, 1) void conv_rows_split_kernel(const u32x4 *__
 // blockIdx % 8 (one XCD) cover 4 row blocks x (4 column blocks x 2 K halves).
 // ---------------------------------------------------------------------------
 constexpr int FCS_K = 11520, FCS_N = 1024, FCS_BK = 64, FCS_SPLIT = 2;
-constexpr int FCS_ROW_CHUNKS = 90 * 32;                      // 16-byte chunks per activation row
+constexpr int FCS_ROW_BYTES = 90 * 512;                      // one activation row: 90 cells x (128 hi + 128 lo halves)
+// LDS slab buffer: 128 rows of 16 pieces of 16 bytes (8 hi, 8 lo) + one pad piece, so that the 16 rows one
+// ds_read_b128 services together fall on 16 different bank groups and every fragment address is the lane's
+// base plus a compile-time offset.
+constexpr int FCS_BR = 6;                                    // weight fragments in flight, in k-steps (+1)
+constexpr int FCS_LROW = 17 * 16;                            // bytes per row in LDS
+constexpr int FCS_LBUF = 128 * FCS_LROW;                     // bytes per buffer
 
-template <int MTR, int BR>
+// ABL (timing experiments only, 0 in the product): 1 no activation loads, 2 no weight loads, 4 no LDS
+// staging writes, 8 no fragment reads.
+template <int MTR, int BR, int ABL = 0>
 __device__ __forceinline__ void fc_split_tile(const u32x4 *__restrict__ a, const float *__restrict__ a_inv_scale,
                                               const u32x4 *__restrict__ wph, const u32x4 *__restrict__ wpl,
                                               const SplitScales *__restrict__ sc, float *__restrict__ part, int count,
-                                              int max_rows, u32x4 (&lds)[3][128 * 16]) {
+                                              int max_rows, unsigned char *lds) {
     const int bid = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, m = lane & 31, h = lane >> 5;
     const int x = bid & 7, i = bid >> 3;
@@ -493,40 +502,49 @@ __device__ __forceinline__ void fc_split_tile(const u32x4 *__restrict__ a, const
     const int nb = (ii >> 2) & 3, ksp = ii >> 4;
     const int row0 = mb * (32 * MTR);
     if (row0 >= count) return;
+    NNB_SP_STAMP(0) NNB_SP_WALL(5)
 
     constexpr int KHALF = FCS_K / FCS_SPLIT;                 // 5760
     constexpr int NSLAB = KHALF / FCS_BK;                    // 90 slabs of 64 k = 4 k-steps each
     constexpr int NKS = NSLAB * 4;
     constexpr int NCH = 2 * MTR;                             // staging chunks per thread and slab (16 rows each)
-    static_assert(NSLAB % 6 == 0, "the slab loop is unrolled by 6 (3 LDS buffers x 2 register sets)");
+    static_assert(NSLAB % 6 == 0 && 24 % BR == 0, "the slab loop is unrolled by 6 (3 LDS buffers x 2 register sets)");
     const int slab0 = ksp * NSLAB;
 
-    // staging map: chunk C of a thread is row 16C + tid/16, 16-byte piece tid%16 (0-7 hi, 8-15 lo)
+    // Addresses are a uniform base (scalar registers, advanced per slab / k-step) plus a per-lane 32-bit offset
+    // that never changes.  Staging: chunk C of a thread is row 16C + tid/16, piece tid%16 (0-7 hi, 8-15 lo).
     const int prow = tid >> 4, pq = tid & 15;
-    const u32x4 *abase[NCH];
-    int sdst[NCH];
+    // (buffer loads: resource = the whole array, scalar offset, per-lane offset, immediate - no 64-bit address math)
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a), 0, max_rows * FCS_ROW_BYTES, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(wph), 0, FCS_K * FCS_N * 2, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(wpl), 0, FCS_K * FCS_N * 2, 0x00027000);
+    const int abase = row0 * FCS_ROW_BYTES;
+    unsigned aoff[NCH];
     static_for<NCH>([&](auto C) __attribute__((always_inline)) {
         constexpr int c = decltype(C)::value;
-        const int srow = 16 * c + prow;
-        const int r = min(row0 + srow, max_rows - 1);
-        abase[c] = a + (size_t)r * FCS_ROW_CHUNKS + (pq & 7) + (pq >> 3) * 16;
-        sdst[c] = srow * 16 + (pq ^ (srow & 15));
+        const int r = min(row0 + 16 * c + prow, max_rows - 1) - row0;
+        aoff[c] = (unsigned)r * FCS_ROW_BYTES + (pq & 7) * 16 + (pq >> 3) * 256;
     });
-    auto slab_off = [&](int s) __attribute__((always_inline)) { const int sg = slab0 + s; return (sg >> 1) * 32 + (sg & 1) * 8; };
+    unsigned char *sdst = lds + prow * FCS_LROW + pq * 16;                   // + c * 16 rows, + buffer
+    auto slab_bytes = [&](int s) __attribute__((always_inline)) { const int sg = slab0 + s; return (sg >> 1) * 512 + (sg & 1) * 128; };
+    auto load_a = [&](int s, unsigned c_off) __attribute__((always_inline)) {
+        return __builtin_amdgcn_raw_buffer_load_b128(ra, (int)c_off, abase + slab_bytes(s), 0);
+    };
 
     u32x4 stg[2][NCH];
     // prologue: slabs 0 and 1 into LDS, slabs 2 and 3 in flight in the two register sets
     static_for<NCH>([&](auto C) __attribute__((always_inline)) {
         constexpr int c = decltype(C)::value;
-        stg[0][c] = abase[c][slab_off(0)]; stg[1][c] = abase[c][slab_off(1)];
+        stg[0][c] = load_a(0, aoff[c]); stg[1][c] = load_a(1, aoff[c]);
     });
     static_for<NCH>([&](auto C) __attribute__((always_inline)) {
         constexpr int c = decltype(C)::value;
-        lds[0][sdst[c]] = stg[0][c]; lds[1][sdst[c]] = stg[1][c];
+        *reinterpret_cast<u32x4 *>(sdst + c * 16 * FCS_LROW) = stg[0][c];
+        *reinterpret_cast<u32x4 *>(sdst + FCS_LBUF + c * 16 * FCS_LROW) = stg[1][c];
     });
     static_for<NCH>([&](auto C) __attribute__((always_inline)) {
         constexpr int c = decltype(C)::value;
-        stg[0][c] = abase[c][slab_off(2)]; stg[1][c] = abase[c][slab_off(3)];
+        stg[0][c] = load_a(2, aoff[c]); stg[1][c] = load_a(3, aoff[c]);
     });
     __syncthreads();
 
@@ -537,23 +555,33 @@ __device__ __forceinline__ void fc_split_tile(const u32x4 *__restrict__ a, const
         for (int r = 0; r < 16; ++r) { acc[t][0][r] = 0.f; acc[t][1][r] = 0.f; }
     });
 
-    // weight fragment of (k-step, column tile): ((kstep*2 + h)*1024 + n) * 16 bytes
-    const size_t wofs = (size_t)(ksp * KHALF / 16) * 2 * FCS_N + h * FCS_N + nb * 256 + w * 64 + m;
-    const u32x4 *wlh = wph + wofs, *wll = wpl + wofs;
+    // weight fragment of (k-step, column tile u): ((kstep*2 + h)*1024 + n) * 16 bytes, n = 256 nb + 64 w + 32 u + m
+    constexpr int WKS = 2 * FCS_N * 16;                      // bytes per k-step
+    const int wbase = ((ksp * KHALF / 16) * 2 * FCS_N + nb * 256) * 16;
+    const int woff = (h * FCS_N + w * 64 + m) * 16;
+    const __amdgpu_buffer_rsrc_t &wbh = rwh, &wbl = rwl;
+    auto load_w = [&](const __amdgpu_buffer_rsrc_t &r, int kstep, int u) __attribute__((always_inline)) {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, woff + u * 512, wbase + kstep * WKS, 0);
+    };
     u32x4 bh[BR][2], bl[BR][2];
     static_for<BR - 1>([&](auto Jc) __attribute__((always_inline)) {
         constexpr int j = decltype(Jc)::value;
-        bh[j][0] = wlh[(size_t)j * 2 * FCS_N]; bh[j][1] = wlh[(size_t)j * 2 * FCS_N + 32];
-        bl[j][0] = wll[(size_t)j * 2 * FCS_N]; bl[j][1] = wll[(size_t)j * 2 * FCS_N + 32];
+        bh[j][0] = load_w(wbh, j, 0); bh[j][1] = load_w(wbh, j, 1);
+        bl[j][0] = load_w(wbl, j, 0); bl[j][1] = load_w(wbl, j, 1);
     });
-    // fragment read offsets (16-byte units) for row tile t: row 32t + m, piece (2*kstep + h) [+8 for lo]
-    int arow[MTR], asw[MTR];
-    u32x4 fh[2][MTR], fl[2][MTR];
+    // fragment of (buffer, row tile t, k-step ks): row 32t + m, piece 2*ks + h (hi), 8 + 2*ks + h (lo)
+    const unsigned char *fbase = lds + m * FCS_LROW + h * 16;
+    auto frag = [&](int buf, int t, int ks, int lo) __attribute__((always_inline)) {
+        return *reinterpret_cast<const u32x4 *>(fbase + buf * FCS_LBUF + t * 32 * FCS_LROW + ks * 32 + lo * 128);
+    };
+    // With 3 or 4 row tiles a tile's fragments are read again right after its last MFMA of the k-step (the
+    // other tiles' MFMAs cover the read); with fewer there is not enough work in between and two sets alternate.
+    constexpr int FSETS = MTR >= 3 ? 1 : 2;
+    u32x4 fh[FSETS][MTR], fl[FSETS][MTR];
     static_for<MTR>([&](auto T) __attribute__((always_inline)) {
         constexpr int t = decltype(T)::value;
-        arow[t] = (t * 32 + m) * 16; asw[t] = (t * 32 + m) & 15;
-        fh[0][t] = lds[0][arow[t] + (h ^ asw[t])];
-        fl[0][t] = lds[0][arow[t] + ((8 + h) ^ asw[t])];
+        fh[0][t] = frag(0, t, 0, 0);
+        fl[0][t] = frag(0, t, 0, 1);
     });
 
     for (int s6 = 0; s6 < NSLAB; s6 += 6) {
@@ -564,13 +592,12 @@ __device__ __forceinline__ void fc_split_tile(const u32x4 *__restrict__ a, const
             static_for<4>([&](auto Kc) __attribute__((always_inline)) {
                 constexpr int ks = decltype(Kc)::value;
                 constexpr int J = U * 4 + ks;                    // k-step inside the 24-step body
-                constexpr int cur = J & 1, nxt = cur ^ 1;
+                constexpr int cur = FSETS == 2 ? (J & 1) : 0, nxt = FSETS == 2 ? (cur ^ 1) : 0;
                 constexpr int slot = J % BR, fill = (J + BR - 1) % BR;
                 int knext = s * 4 + ks + BR - 1;
                 knext = knext < NKS ? knext : NKS - 1;
                 constexpr int nbuf = ks < 3 ? buf : (U + 1) % 3; // where the next k-step's fragments live
                 constexpr int nks = (ks + 1) & 3;
-                const bool have_next = ks < 3 || s + 1 < NSLAB;
                 static_for<MTR>([&](auto T) __attribute__((always_inline)) {
                     constexpr int t = decltype(T)::value;
                     static_for<2>([&](auto Uu) __attribute__((always_inline)) {
@@ -581,23 +608,22 @@ __device__ __forceinline__ void fc_split_tile(const u32x4 *__restrict__ a, const
                         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, acc[t][u], 0, 0, 0);
                         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, acc[t][u], 0, 0, 0);
                         // two memory instructions behind every MFMA triple
-                        if constexpr (t == 0) {                  // weights of k-step J + BR - 1
-                            bh[fill][u] = wlh[(size_t)knext * 2 * FCS_N + 32 * u];
-                            bl[fill][u] = wll[(size_t)knext * 2 * FCS_N + 32 * u];
+                        if constexpr (t == 0 && !(ABL & 2)) {    // weights of k-step J + BR - 1
+                            bh[fill][u] = load_w(wbh, knext, u);
+                            bl[fill][u] = load_w(wbl, knext, u);
                         }
-                        if constexpr (u == 1) {                  // fragments of the next k-step, row tile t
-                            if (have_next) {
-                                fh[nxt][t] = lds[nbuf][arow[t] + ((2 * nks + h) ^ asw[t])];
-                                fl[nxt][t] = lds[nbuf][arow[t] + ((8 + 2 * nks + h) ^ asw[t])];
-                            }
+                        if constexpr (u == 1 && !(ABL & 8)) {    // fragments of the next k-step, row tile t
+                            fh[nxt][t] = frag(nbuf, t, nks, 0);     // (after the last k-step: read, never used)
+                            fl[nxt][t] = frag(nbuf, t, nks, 1);
                         }
-                        if constexpr (u == 0 && ks < 2) {        // slab s+2: registers -> LDS
+                        if constexpr (u == 0 && ks < 2 && !(ABL & 4)) {   // slab s+2: registers -> LDS
                             constexpr int c = ks * MTR + t;
-                            if (s + 2 < NSLAB) lds[(U + 2) % 3][sdst[c]] = stg[set][c];
+                            // (past the last slab this rewrites a buffer nobody reads any more)
+                            *reinterpret_cast<u32x4 *>(sdst + ((U + 2) % 3) * FCS_LBUF + c * 16 * FCS_LROW) = stg[set][c];
                         }
-                        if constexpr (u == 0 && ks >= 2) {       // slab s+4: global -> registers
+                        if constexpr (u == 0 && ks >= 2 && !(ABL & 1)) {  // slab s+4: global -> registers
                             constexpr int c = (ks - 2) * MTR + t;
-                            if (s + 4 < NSLAB) stg[set][c] = abase[c][slab_off(s + 4)];
+                            stg[set][c] = load_a(s + 4 < NSLAB ? s + 4 : NSLAB - 1, aoff[c]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     });
@@ -607,6 +633,7 @@ __device__ __forceinline__ void fc_split_tile(const u32x4 *__restrict__ a, const
         });
     }
 
+    NNB_SP_STAMP(3) NNB_SP_WALL(6)
     // epilogue: back to true units with the row's activation scale and the layer's weight scale
     const float inv_sw = sc->inv_swf;
     float *obase = part + (size_t)ksp * max_rows * FCS_N + nb * 256 + w * 64 + m;
@@ -624,6 +651,7 @@ __device__ __forceinline__ void fc_split_tile(const u32x4 *__restrict__ a, const
     });
 }
 
+template <int BR, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void fc_split_kernel(const u32x4 *__restrict__ a,          // [rows][90][32 chunks]
                                                           const float *__restrict__ a_inv_scale, // [rows]
                                                           const u32x4 *__restrict__ wph, const u32x4 *__restrict__ wpl,
@@ -631,14 +659,14 @@ __global__ __launch_bounds__(256, 1) void fc_split_kernel(const u32x4 *__restric
                                                           float *__restrict__ part,              // [2][max_rows][1024]
                                                           const int32_t *__restrict__ count_ptr, int n_fixed,
                                                           int max_rows) {
-    __shared__ __attribute__((aligned(16))) u32x4 lds[3][128 * 16];     // 128 rows x (64 hi + 64 lo halves), 3 buffers
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * FCS_LBUF];    // three slab buffers
     const int count = batch_count_sp(count_ptr, n_fixed);
     const int mblocks = gridDim.x >> 3;                      // row blocks the grid provides (8 column/K blocks each)
     const int tiles = (count + 32 * mblocks - 1) / (32 * mblocks);
-    if (tiles <= 1) fc_split_tile<1, 4>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds);
-    else if (tiles == 2) fc_split_tile<2, 4>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds);
-    else if (tiles == 3) fc_split_tile<3, 4>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds);
-    else fc_split_tile<4, 4>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds);
+    if (tiles <= 1) fc_split_tile<1, BR, ABL>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds);
+    else if (tiles == 2) fc_split_tile<2, BR, ABL>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds);
+    else if (tiles == 3) fc_split_tile<3, BR, ABL>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds);
+    else fc_split_tile<4, BR, ABL>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds);
 }
 
 // Activations of the split path back to float32 [n][cells][128] (tests and debugging only).
@@ -709,7 +737,7 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
         break;
     case NET_FC: {
         int groups = cdiv_sp(cdiv_sp(n_max, 128), 32);       // 32 row blocks per group of 256 blocks
-        fc_split_kernel<<<256 * groups, 256, 0, st>>>(a3, b.act3_inv, (const u32x4 *)w.fc_wh, (const u32x4 *)w.fc_wl,
+        fc_split_kernel<FCS_BR><<<256 * groups, 256, 0, st>>>(a3, b.act3_inv, (const u32x4 *)w.fc_wh, (const u32x4 *)w.fc_wl,
                                                       w.sp_scales, b.fcpart, count_ptr, n_max, b.max_rows);
         break;
     }

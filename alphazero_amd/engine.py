@@ -46,7 +46,7 @@ class Engine:
     """One engine = one GPU, one workspace, up to `max_games` concurrent games."""
 
     def __init__(self, max_games: int, max_sims: int, device: Optional[torch.device] = None,
-                 n_weight_sets: int = 1, precision: str = "f16", eval_cache_slots: int = 0):
+                 n_weight_sets: int = 1, precision: str = "f32s", eval_cache_slots: int = 0):
         if not torch.cuda.is_available():
             raise NnbError("no GPU visible: the engine runs on an MI355X only (there is no CPU path)")
         self.lib = _lib.load()

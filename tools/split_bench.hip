@@ -98,10 +98,23 @@ int main(int argc, char **argv) {
         }
     }
     u32x4 *a3 = dev_random_halves<u32x4>((size_t)n * 90 * 256, 0.f, 1.f, 8);
-    us = time_it([&] {
-        int groups = cdiv_sp(cdiv_sp(n, 128), 32);
-        fc_split_kernel<<<256 * groups, 256, 0, 0>>>(a3, inv, wfh, wfl, sc, part, nullptr, n, n);
-    });
-    printf("%-34s %8.1f us  %7.1f TFLOP/s\n", "linear 11520->1024", us, (double)n * 2 * 11520 * 1024 / (us * 1e-6) / 1e12);
+    auto fc_run = [&](auto BRc, auto ABLc, int rows) {
+        constexpr int BR = decltype(BRc)::value, ABL = decltype(ABLc)::value;
+        float t = time_it([&] {
+            int groups = cdiv_sp(cdiv_sp(rows, 128), 32);
+            fc_split_kernel<BR, ABL><<<256 * groups, 256, 0, 0>>>(a3, inv, wfh, wfl, sc, part, nullptr, rows, n);
+        });
+        unsigned long long h[8]; CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sp_clk), sizeof h));
+        printf("linear 11520->1024, %4d rows, ring %d, ablate %2d: %8.1f us  %7.1f TFLOP/s  block %llu cycles, clock %.0f MHz\n", rows, BR, ABL, t,
+               (double)rows * 2 * 11520 * 1024 / (t * 1e-6) / 1e12, h[3] - h[0], (double)(h[3] - h[0]) / (double)(h[6] - h[5]) * 100.0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    fc_run(std::integral_constant<int, 8>{}, I0{}, n);
+    fc_run(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{}, n);
+    fc_run(std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{}, n);
+    fc_run(std::integral_constant<int, 8>{}, std::integral_constant<int, 5>{}, n);
+    fc_run(std::integral_constant<int, 8>{}, std::integral_constant<int, 8>{}, n);
+    fc_run(std::integral_constant<int, 8>{}, std::integral_constant<int, 15>{}, n);
+    fc_run(std::integral_constant<int, 6>{}, I0{}, n / 2);
     return 0;
 }
