@@ -38,7 +38,8 @@ class SearchParams(C.Structure):
 class RoundStats(C.Structure):
     _fields_ = [("games", C.c_int64), ("plies", C.c_int64), ("sims", C.c_int64),
                 ("net_leaves", C.c_int64), ("terminal_hits", C.c_int64), ("depth_sum", C.c_int64),
-                ("steps", C.c_int64), ("moves_rounds", C.c_int64), ("cache_hits", C.c_int64)]
+                ("steps", C.c_int64), ("moves_rounds", C.c_int64), ("cache_hits", C.c_int64),
+                ("chains", C.c_int64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

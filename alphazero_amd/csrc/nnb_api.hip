@@ -417,7 +417,8 @@ int run_move(nnb_engine *e, hipStream_t st, const nnb_search_params &p, int32_t 
     return NNB_OK;
 }
 
-int collect_stats(nnb_engine *e, hipStream_t st, nnb_round_stats *out, long long steps, long long rounds, int n) {
+int collect_stats(nnb_engine *e, hipStream_t st, nnb_round_stats *out, long long steps, long long rounds, int n,
+                  int chains = 1) {
     HIP_TRY(hipMemsetAsync(e->dev.stats64, 0, 8 * sizeof(unsigned long long), st));
     launch_stats_reduce(st, e->dev);
     HIP_TRY(hipMemcpyAsync(e->host_stats, e->dev.stats64, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -433,6 +434,7 @@ int collect_stats(nnb_engine *e, hipStream_t st, nnb_round_stats *out, long long
         out->cache_hits = (int64_t)e->host_stats[5];
         out->steps = steps;
         out->moves_rounds = rounds;
+        out->chains = chains;
     }
     return NNB_OK;
 }
@@ -824,7 +826,7 @@ int nnb_selfplay_round(nnb_engine *e, void *stream, const nnb_search_params *par
             live = e->host_counters[0];
         }
         rounds = (steps + params->sims) / (params->sims + 1);
-        rc = collect_stats(e, st, stats_out, steps, rounds, n_games);
+        rc = collect_stats(e, st, stats_out, steps, rounds, n_games, halves ? 2 : 1);
         if (rc) return rc;
         if (live > 0)
             return fail(NNB_ERR_STATE, "self-play stopped after %lld lock-step rounds with %d games unfinished "

@@ -239,8 +239,11 @@ class Engine:
         """Plays n_games games to the end.  Returns (trajectory bytes on device [n, 1376] uint8, stats)."""
         sb = sp = None
         if start_boards is not None:
-            sb = self._dev(np.asarray(start_boards, dtype=np.uint64).reshape(-1, 2), torch.int64)
-            sp = self._dev(np.asarray(start_players, dtype=np.int8), torch.int8)
+            # device tensors (int64 bit patterns of the boards, int8 movers) are used where they lie
+            sb = self._dev(start_boards if isinstance(start_boards, torch.Tensor)
+                           else np.asarray(start_boards, dtype=np.uint64), torch.int64).reshape(-1, 2)
+            sp = self._dev(start_players if isinstance(start_players, torch.Tensor)
+                           else np.asarray(start_players, dtype=np.int8), torch.int8)
             if sb.shape[0] != n_games or sp.shape[0] != n_games:
                 raise ValueError("start positions must have n_games rows")
         traj = out if out is not None else torch.empty((n_games, TRAJECTORY_BYTES), dtype=torch.uint8,

@@ -171,6 +171,8 @@ typedef struct nnb_round_stats {
     int64_t steps;               /* lock-step iterations (tree kernel + forward)    */
     int64_t moves_rounds;        /* move rounds (<= 42)                             */
     int64_t cache_hits;          /* simulations answered by the evaluation cache    */
+    int64_t chains;              /* tree step -> forward pass chains a lock-step round was split in (1, or 2
+                                    halves on two streams): kernel launches per class = steps * chains      */
 } nnb_round_stats;
 
 /* ---- library ----------------------------------------------------------- */
