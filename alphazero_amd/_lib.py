@@ -39,7 +39,7 @@ class RoundStats(C.Structure):
     _fields_ = [("games", C.c_int64), ("plies", C.c_int64), ("sims", C.c_int64),
                 ("net_leaves", C.c_int64), ("terminal_hits", C.c_int64), ("depth_sum", C.c_int64),
                 ("steps", C.c_int64), ("moves_rounds", C.c_int64), ("cache_hits", C.c_int64),
-                ("chains", C.c_int64)]
+                ("chains", C.c_int64), ("finished_total", C.c_int64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -70,6 +70,8 @@ SIGNATURES = {
     "nnb_dirichlet_noise": (C.c_int, [_P, C.c_int32, C.c_uint64, _P, _P, _P, C.c_double, _P]),
     "nnb_selfplay_round": (C.c_int, [_P, _P, C.POINTER(SearchParams), C.c_int32, C.c_int32, _P, _P,
                                      _P, C.POINTER(RoundStats)]),
+    "nnb_selfplay_stream": (C.c_int, [_P, _P, C.POINTER(SearchParams), C.c_int32, C.c_int32, C.c_int32, _P, _P,
+                                      C.c_int32, _P, _P, C.c_int32, C.POINTER(RoundStats)]),
     "nnb_profile_enable": (C.c_int, [_P, C.c_int]),
     "nnb_profile_reset": (C.c_int, [_P]),
     "nnb_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

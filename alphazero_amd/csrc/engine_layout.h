@@ -83,15 +83,21 @@ struct EngineDev {
 
 // A self-play round: `total_games` games are played on n_games <= total_games slots; a slot whose
 // game ends takes the next unplayed game, n_games + counters[kRefills]++, until none is left.
+// Game j starts from start position j % n_starts and is recorded in traj[j % ring_len] (a plain round
+// has n_starts = ring_len = total_games; an endless stream of games wraps around both).
 struct RoundDev {
-    const u64 *start_boards;    // [total_games][2] or null (empty boards)
-    const int8_t *start_players; // [total_games] or null (colour 1 starts)
-    nnb_trajectory *traj;       // [total_games]
+    const u64 *start_boards;    // [n_starts][2] or null (empty boards)
+    const int8_t *start_players; // [n_starts] or null (colour 1 starts)
+    nnb_trajectory *traj;       // [ring_len]
     int32_t total_games;
     int32_t first_game_id;
+    int32_t ring_len;
+    int32_t n_starts;
+    int32_t *finished_ring;     // [ring_len] or null: entry k % ring_len = record index of the k-th game to finish
 };
 constexpr int kRefills = 16;    // index into EngineDev::counters; entries 0..15 are cleared every move
 constexpr int kLive = 17;       // slots that still hold a game (kept through a whole round)
+constexpr int kFinished = 18;   // games finished since the round was set up (directly behind kLive: read together)
 
 // Games [first, end) and the leaf batch they file their leaves in (-1: by the root mover's weight set).
 struct GameSpan {

@@ -79,6 +79,14 @@ struct nnb_engine {
     size_t fused_lds_prepared = 0;
     hipStream_t side_stream = nullptr;     // second forward pass of a two-network arena
     hipEvent_t fork_event = nullptr, join_event = nullptr;
+    // nnb_selfplay_stream: games stay seated between calls
+    bool stream_on = false;
+    int stream_slots = 0;
+    long long stream_steps = 0;            // lock-step rounds since the restart (their parity selects the leaf buffers)
+    long long stream_finished = 0;         // games finished since the restart, as of the last call's end
+    long long stream_prev[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // cumulative statistics as of the last call's end
+    nnb_search_params stream_params = {};
+    RoundDev stream_round = {};
     bool prof_on = false;
     bool prof_events = false;
     int prof_stride = 1;
@@ -510,6 +518,101 @@ int static_state(hipStream_t st, StaticState **out) {
     return NNB_OK;
 }
 
+// Root noise is drawn on the device when AZ mode asks for it: *make_noise = 1.
+int noise_wanted(const nnb_search_params &p, int *make_noise) {
+    *make_noise = 0;
+    if (p.mode == NNB_MODE_AZ && p.dirichlet_eps > 0.0) {
+        if (!(p.dirichlet_alpha > 0.0)) return fail(NNB_ERR_ARG, "dirichlet_eps > 0 needs dirichlet_alpha > 0");
+        *make_noise = 1;
+    }
+    return NNB_OK;
+}
+
+SearchDev lockstep_search_dev(const nnb_search_params &p) {
+    SearchDev sd = to_dev(p);
+    if (p.mode != NNB_MODE_AZ) { sd.dirichlet_eps = 0.0; sd.dirichlet_alpha = 0.0; }
+    return sd;
+}
+
+// Self-play without a common move boundary: before every tree step the turnover (a kernel of its own when
+// root noise has to be drawn, otherwise part of the step) ends the move of the games whose budget is used up
+// and starts their next search; the host only looks at the device counters every kChunk rounds.  Runs
+// lock-step rounds step0, step0+1, ... (the round's parity selects the leaf buffers) until no slot holds a
+// game, or `finish_target` >= 0 games have finished since the round's set-up, or max_steps rounds have run in
+// this call.  *steps_out = rounds run here, *live_out = occupied slots, *finished_out = games finished since
+// the set-up.
+int run_free_rounds(nnb_engine *e, hipStream_t st, const nnb_search_params &params, const RoundDev &round,
+                    int make_noise, long long step0, long long max_steps, long long finish_target,
+                    long long *steps_out, int *live_out, long long *finished_out, int *chains_out) {
+    const nnb_search_params *p = &params;
+    SearchDev sd = lockstep_search_dev(params);
+    const int slots = e->dev.n_games;
+    StepPlan plan = make_step_plan(e, params, sd);
+    constexpr int kChunk = 64;
+    e->prof_stride = kChunk / kProfSamples + 1;
+    long long steps = 0;
+    HIP_TRY(hipMemcpyAsync(e->host_counters, e->dev.counters + kLive, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    int live = e->host_counters[0];
+    long long finished = (unsigned)e->host_counters[1];
+    auto go_on = [&]() { return live > 0 && steps < max_steps && (finish_target < 0 || finished < finish_target); };
+    auto look = [&]() -> hipError_t {
+        hipError_t err = hipGetLastError();
+        if (err != hipSuccess) return err;
+        err = hipMemcpyAsync(e->host_counters, e->dev.counters + kLive, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (err != hipSuccess) return err;
+        err = hipStreamSynchronize(st);
+        if (err != hipSuccess) return err;
+        prof_drain(e);
+        live = e->host_counters[0];
+        finished = (unsigned)e->host_counters[1];
+        return hipSuccess;
+    };
+    // One network and enough slots: the slots are split in two halves, each with a leaf batch, activation
+    // buffers and a stream of its own, and each half runs its own tree step -> forward pass chain.  The two
+    // chains are not synchronised with each other, so one half's tree step runs under the other half's forward
+    // pass, and the CUs that the last blocks of one kernel leave idle take blocks of the other half's kernels.
+    // Games do not interact, so the records are the same byte for byte.
+    // Measured on 4096 slots x 200 simulations: +5 % games/s with the float32-faithful kernels (one block per CU,
+    // long tails), -3 % with the half-input kernels (two blocks per CU already overlap), so those keep one chain.
+    const bool wanted = (p->flags & NNB_FLAG_TWO_STREAMS) ||
+                        (slots >= kHalvesMinSlots && e->cfg.net_precision != NNB_NET_F16);
+    const bool halves = plan.nbatch == 1 && slots >= 2 * kStepGamesHost && wanted && !(p->flags & NNB_FLAG_ONE_STREAM);
+    if (halves) {
+        const int mid = (slots / 2 + kStepGamesHost - 1) / kStepGamesHost * kStepGamesHost;
+        const GameSpan span[2] = {{0, mid, 0}, {mid, slots, 1}};
+        if (plan.heads.fused) plan.heads.h[1] = heads_input(e, sd.wset[0], 1);
+        hipStream_t hs[2] = {st, e->side_stream};
+        while (go_on()) {
+            (void)hipEventRecord(e->fork_event, st);
+            (void)hipStreamWaitEvent(e->side_stream, e->fork_event, 0);
+            for (int k = 0; k < kChunk; ++k, ++steps) {
+                const int parity = (int)((step0 + steps) & 1);
+                for (int b = 0; b < 2; ++b) {
+                    if (make_noise) launch_turnover(hs[b], e->dev, sd, round, make_noise, &span[b]);
+                    { ProfScope ps(e, 0, hs[b]); launch_tree_step(hs[b], e->dev, sd, parity, plan.heads, make_noise ? nullptr : &round, &span[b]); }
+                    if (p->evaluator == NNB_EVAL_NET)
+                        forward_leaves(e, hs[b], sd.wset[0], b, parity, span[b].end - span[b].first, !plan.heads.fused);
+                    else
+                        launch_fixed_eval(hs[b], e->dev, sd, b, parity);
+                }
+            }
+            (void)hipEventRecord(e->join_event, e->side_stream);
+            (void)hipStreamWaitEvent(st, e->join_event, 0);
+            HIP_TRY(look());
+        }
+    }
+    while (!halves && go_on()) {
+        for (int k = 0; k < kChunk; ++k, ++steps) {
+            if (make_noise) launch_turnover(st, e->dev, sd, round, make_noise);
+            lockstep_step(e, st, params, sd, plan, (int)((step0 + steps) & 1), true, make_noise ? nullptr : &round);
+        }
+        HIP_TRY(look());
+    }
+    *steps_out = steps; *live_out = live; *finished_out = finished; *chains_out = halves ? 2 : 1;
+    return NNB_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -663,6 +766,7 @@ int nnb_net_forward(nnb_engine *e, int weight_set, void *stream, int32_t n, cons
     if (n == 0) return NNB_OK;
     if (!side_boards) return fail(NNB_ERR_ARG, "side_boards is null");
     if (priors_out && !legal_masks) return fail(NNB_ERR_ARG, "priors_out needs legal_masks");
+    e->stream_on = false;                                // the activations of a seated stream's pending leaves are overwritten
     hipStream_t st = static_cast<hipStream_t>(stream);
     const NetWeights &w = e->weights[weight_set];
     const u64 *side = reinterpret_cast<const u64 *>(side_boards);
@@ -723,6 +827,7 @@ int nnb_search(nnb_engine *e, void *stream, const nnb_search_params *params, int
     if (!root_colour_boards || !root_players) return fail(NNB_ERR_ARG, "root boards / players is null");
     hipStream_t st = static_cast<hipStream_t>(stream);
     e->dev.n_games = n;
+    e->stream_on = false;
     launch_search_init(st, e->dev, reinterpret_cast<const u64 *>(root_colour_boards), root_players, side_players,
                        params->rng_game_base, root_noise);
     long long steps = 0;
@@ -749,7 +854,8 @@ int nnb_selfplay_round(nnb_engine *e, void *stream, const nnb_search_params *par
     hipStream_t st = static_cast<hipStream_t>(stream);
     e->dev.n_games = slots;
     const RoundDev round = {reinterpret_cast<const u64 *>(start_colour_boards), start_players, trajectories_out, n_games,
-                            first_game_id};
+                            first_game_id, n_games, n_games, nullptr};
+    e->stream_on = false;
     HIP_TRY(hipMemsetAsync(e->dev.counters, 0, 32 * sizeof(int32_t), st));      // live count and refill count
     launch_selfplay_init(st, e->dev, round);
     HIP_TRY(hipMemcpyAsync(e->host_counters, e->dev.counters, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -758,75 +864,19 @@ int nnb_selfplay_round(nnb_engine *e, void *stream, const nnb_search_params *par
     int live = e->host_counters[0];
     const bool lockstep = params->evaluator == NNB_EVAL_NET || (params->flags & NNB_FLAG_LOCKSTEP);
     if (lockstep && !(params->flags & NNB_FLAG_SYNC_MOVES)) {
-        // No common move boundary: before every tree step the turnover kernel ends the move of the
-        // games whose budget is used up and starts their next search; the host only looks at the
-        // number of occupied slots every kChunk rounds.
-        SearchDev sd = to_dev(*params);
-        const bool az = params->mode == NNB_MODE_AZ;
-        if (!az) { sd.dirichlet_eps = 0.0; sd.dirichlet_alpha = 0.0; }
         int make_noise = 0;
-        if (az && sd.dirichlet_eps > 0.0) {
-            if (!(sd.dirichlet_alpha > 0.0)) return fail(NNB_ERR_ARG, "dirichlet_eps > 0 needs dirichlet_alpha > 0");
-            make_noise = 1;
-        }
-        StepPlan plan = make_step_plan(e, *params, sd);
-        constexpr int kChunk = 64;
-        e->prof_stride = kChunk / kProfSamples + 1;
+        rc = noise_wanted(*params, &make_noise);
+        if (rc) return rc;
+        SearchDev sd = lockstep_search_dev(*params);
         launch_tree_init(st, e->dev, sd, make_noise, 1);
         long long max_steps = ((long long)n_games / (slots > 0 ? slots : 1) + 2) * (kMaxPlies + 1) * (params->sims + 1);
         if (params->round_limit > 0 && params->round_limit < max_steps) max_steps = params->round_limit;
-        // One network and enough slots: the slots are split in two halves, each with a leaf batch, activation
-        // buffers and a stream of its own, and each half runs its own tree step -> forward pass chain.  The two
-        // chains are not synchronised with each other, so one half's tree step runs under the other half's forward
-        // pass, and the CUs that the last blocks of one kernel leave idle take blocks of the other half's kernels.
-        // Games do not interact, so the records are the same byte for byte.
-        // Measured on 4096 slots x 200 simulations: +5 % games/s with the float32-faithful kernels (one block per CU,
-        // long tails), -3 % with the half-input kernels (two blocks per CU already overlap), so those keep one chain.
-        const bool wanted = (params->flags & NNB_FLAG_TWO_STREAMS) ||
-                            (slots >= kHalvesMinSlots && e->cfg.net_precision != NNB_NET_F16);
-        const bool halves = plan.nbatch == 1 && slots >= 2 * kStepGamesHost && wanted && !(params->flags & NNB_FLAG_ONE_STREAM);
-        if (halves) {
-            const int mid = (slots / 2 + kStepGamesHost - 1) / kStepGamesHost * kStepGamesHost;
-            const GameSpan span[2] = {{0, mid, 0}, {mid, slots, 1}};
-            if (plan.heads.fused) plan.heads.h[1] = heads_input(e, sd.wset[0], 1);
-            hipStream_t hs[2] = {st, e->side_stream};
-            while (live > 0 && steps < max_steps) {
-                (void)hipEventRecord(e->fork_event, st);
-                (void)hipStreamWaitEvent(e->side_stream, e->fork_event, 0);
-                for (int k = 0; k < kChunk; ++k, ++steps) {
-                    const int parity = (int)(steps & 1);
-                    for (int b = 0; b < 2; ++b) {
-                        if (make_noise) launch_turnover(hs[b], e->dev, sd, round, make_noise, &span[b]);
-                        { ProfScope ps(e, 0, hs[b]); launch_tree_step(hs[b], e->dev, sd, parity, plan.heads, make_noise ? nullptr : &round, &span[b]); }
-                        if (params->evaluator == NNB_EVAL_NET)
-                            forward_leaves(e, hs[b], sd.wset[0], b, parity, span[b].end - span[b].first, !plan.heads.fused);
-                        else
-                            launch_fixed_eval(hs[b], e->dev, sd, b, parity);
-                    }
-                }
-                (void)hipEventRecord(e->join_event, e->side_stream);
-                (void)hipStreamWaitEvent(st, e->join_event, 0);
-                HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemcpyAsync(e->host_counters, e->dev.counters + kLive, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                prof_drain(e);
-                live = e->host_counters[0];
-            }
-        }
-        while (!halves && live > 0 && steps < max_steps) {
-            for (int k = 0; k < kChunk; ++k, ++steps) {
-                // with root noise to draw the turnover is a launch of its own, otherwise part of the step
-                if (make_noise) launch_turnover(st, e->dev, sd, round, make_noise);
-                lockstep_step(e, st, *params, sd, plan, (int)(steps & 1), true, make_noise ? nullptr : &round);
-            }
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(e->host_counters, e->dev.counters + kLive, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            prof_drain(e);
-            live = e->host_counters[0];
-        }
+        int chains = 1;
+        long long finished = 0;
+        rc = run_free_rounds(e, st, *params, round, make_noise, 0, max_steps, -1, &steps, &live, &finished, &chains);
+        if (rc) return rc;
         rounds = (steps + params->sims) / (params->sims + 1);
-        rc = collect_stats(e, st, stats_out, steps, rounds, n_games, halves ? 2 : 1);
+        rc = collect_stats(e, st, stats_out, steps, rounds, n_games, chains);
         if (rc) return rc;
         if (live > 0)
             return fail(NNB_ERR_STATE, "self-play stopped after %lld lock-step rounds with %d games unfinished "
@@ -849,6 +899,87 @@ int nnb_selfplay_round(nnb_engine *e, void *stream, const nnb_search_params *par
     if (live > 0)
         return fail(NNB_ERR_STATE, "self-play stopped after %lld move rounds with %d games unfinished "
                     "(their records have result = 2)", rounds, live);
+    return NNB_OK;
+}
+
+int nnb_selfplay_stream(nnb_engine *e, void *stream, const nnb_search_params *params, int32_t restart,
+                        int32_t first_game_id, int32_t min_finished, const uint64_t *start_colour_boards,
+                        const int8_t *start_players, int32_t n_starts, nnb_trajectory *record_ring,
+                        int32_t *finished_ring, int32_t ring_len, nnb_round_stats *stats_out) {
+    if (!e) return fail(NNB_ERR_ARG, "engine is null");
+    if (min_finished < 0) return fail(NNB_ERR_ARG, "min_finished < 0");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (restart) {
+        const int slots = e->cfg.max_games;
+        int rc = check_params(e, params, slots);
+        if (rc) return rc;
+        if (params->evaluator != NNB_EVAL_NET && !(params->flags & NNB_FLAG_LOCKSTEP))
+            return fail(NNB_ERR_ARG, "a stream of games runs lock-step rounds: a fixed evaluator needs NNB_FLAG_LOCKSTEP");
+        if (params->flags & NNB_FLAG_SYNC_MOVES) return fail(NNB_ERR_ARG, "a stream of games has no common move boundary (NNB_FLAG_SYNC_MOVES)");
+        if (!record_ring) return fail(NNB_ERR_ARG, "record_ring is null");
+        if (ring_len < 4 * slots) return fail(NNB_ERR_ARG, "ring_len = %d: the record ring needs at least 4 x max_games = %d records", ring_len, 4 * slots);
+        if ((start_colour_boards == nullptr) != (start_players == nullptr))
+            return fail(NNB_ERR_ARG, "start boards and start players must be given together");
+        if (start_colour_boards && n_starts < 1) return fail(NNB_ERR_ARG, "n_starts < 1");
+        e->stream_on = false;
+        e->dev.n_games = slots;
+        e->stream_round = RoundDev{reinterpret_cast<const u64 *>(start_colour_boards), start_players, record_ring,
+                                   0x7fffffff - slots, first_game_id, ring_len, start_colour_boards ? n_starts : 1,
+                                   finished_ring};
+        int make_noise = 0;
+        rc = noise_wanted(*params, &make_noise);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(e->dev.counters, 0, 32 * sizeof(int32_t), st));
+        launch_selfplay_init(st, e->dev, e->stream_round);
+        launch_tree_init(st, e->dev, lockstep_search_dev(*params), make_noise, 1);
+        HIP_TRY(hipGetLastError());
+        e->stream_params = *params;
+        e->stream_slots = slots;
+        e->stream_steps = 0;
+        e->stream_finished = 0;
+        for (auto &v : e->stream_prev) v = 0;
+        e->stream_on = true;
+    } else {
+        if (!e->stream_on)
+            return fail(NNB_ERR_STATE, "no stream of games is seated on this engine (never started, or another call "
+                        "has used the engine since): call with restart = 1");
+        if (params && memcmp(params, &e->stream_params, sizeof *params) != 0)
+            return fail(NNB_ERR_ARG, "the search parameters differ from those the stream was started with");
+    }
+    const nnb_search_params &p = e->stream_params;
+    e->dev.n_games = e->stream_slots;
+    int make_noise = 0;
+    (void)noise_wanted(p, &make_noise);
+    long long max_steps = ((long long)min_finished / e->stream_slots + 2) * (kMaxPlies + 1) * (p.sims + 1);
+    if (p.round_limit > 0 && p.round_limit < max_steps) max_steps = p.round_limit;
+    long long steps = 0, finished = e->stream_finished;
+    int live = 0, chains = 1;
+    int rc = run_free_rounds(e, st, p, e->stream_round, make_noise, e->stream_steps, max_steps,
+                             e->stream_finished + min_finished, &steps, &live, &finished, &chains);
+    if (rc) { e->stream_on = false; return rc; }
+    e->stream_steps += steps;
+    nnb_round_stats total;
+    rc = collect_stats(e, st, &total, steps, (steps + p.sims) / (p.sims + 1), 0, chains);
+    if (rc) { e->stream_on = false; return rc; }
+    long long *prev = e->stream_prev;
+    const long long now[6] = {total.depth_sum, total.terminal_hits, total.net_leaves, total.sims, total.plies, total.cache_hits};
+    if (stats_out) {
+        *stats_out = total;
+        stats_out->games = finished - e->stream_finished;
+        stats_out->depth_sum = now[0] - prev[0];
+        stats_out->terminal_hits = now[1] - prev[1];
+        stats_out->net_leaves = now[2] - prev[2];
+        stats_out->sims = now[3] - prev[3];
+        stats_out->plies = now[4] - prev[4];
+        stats_out->cache_hits = now[5] - prev[5];
+        stats_out->finished_total = finished;
+    }
+    for (int k = 0; k < 6; ++k) prev[k] = now[k];
+    const long long got = finished - e->stream_finished;
+    e->stream_finished = finished;
+    if (got < min_finished)
+        return fail(NNB_ERR_STATE, "the stream stopped after %lld lock-step rounds with %lld of the %d games asked for finished",
+                    steps, got, min_finished);
     return NNB_OK;
 }
 

@@ -733,19 +733,27 @@ __global__ __launch_bounds__(64) void tree_fused_kernel(EngineDev e, SearchDev p
 // ---------------------------------------------------------------------------
 // Puts game j of the round into slot g; returns false when that game starts from a finished
 // position (its record is then complete and the slot is still free).
+// A game's record is complete: count it and, if the caller keeps one, append it to the completion list.
+__device__ void note_finished(const EngineDev &e, const RoundDev &r, int record) {
+    const unsigned k = (unsigned)atomicAdd(&e.counters[kFinished], 1);
+    if (r.finished_ring) r.finished_ring[k % (unsigned)r.ring_len] = record;
+}
+
 __device__ bool seat_game(const EngineDev &e, const RoundDev &r, int g, int j) {
     // caller-supplied positions are reduced to something the kernels can index safely: only
     // the 42 playable bits, no cell owned twice, mover 1 or 2
-    u64 b1 = r.start_boards ? r.start_boards[2 * j] & c4::kBoardMask : 0;
-    u64 b2 = r.start_boards ? r.start_boards[2 * j + 1] & c4::kBoardMask & ~b1 : 0;
-    int player = r.start_players ? (r.start_players[j] == 2 ? 2 : 1) : 1;
-    nnb_trajectory *t = r.traj + j;
+    const int js = j % r.n_starts, jt = j % r.ring_len;
+    u64 b1 = r.start_boards ? r.start_boards[2 * js] & c4::kBoardMask : 0;
+    u64 b2 = r.start_boards ? r.start_boards[2 * js + 1] & c4::kBoardMask & ~b1 : 0;
+    int player = r.start_players ? (r.start_players[js] == 2 ? 2 : 1) : 1;
+    nnb_trajectory *t = r.traj + jt;
     t->length = 0; t->result = 2; t->game_id = r.first_game_id + j; t->reserved = 0;
     t->final_boards[0] = b1; t->final_boards[1] = b2;
     uint4 *z = reinterpret_cast<uint4 *>(t->plies);           // plies past `length` read as zero
     for (int k = 0; k < (int)(sizeof(t->plies) / (sizeof(uint4))); ++k) z[k] = make_uint4(0, 0, 0, 0);
     if (c4::is_terminal(b1, b2)) {
         t->result = c4::result(b1, b2);
+        note_finished(e, r, jt);
         return false;
     }
     e.root_boards[2 * g] = b1; e.root_boards[2 * g + 1] = b2;
@@ -753,7 +761,7 @@ __device__ bool seat_game(const EngineDev &e, const RoundDev &r, int g, int j) {
     e.root_side[g] = 0;                                       // self-play: SearchDev::side decides
     e.ply[g] = 0;
     e.game_id[g] = r.first_game_id + j;
-    e.traj_index[g] = j;
+    e.traj_index[g] = jt;
     e.cache_gen[g] += 1;                                      // the new game starts with an empty evaluation cache
     return true;
 }
@@ -803,6 +811,8 @@ __device__ void readout_game(const EngineDev &e, const SearchDev &p, int g, int3
         t->final_boards[0] = b1; t->final_boards[1] = b2;
         e.game_stats[8 * g + 4] += ply;
         e.ply[g] = 0;
+        __threadfence();                                          // the record is complete before it is listed
+        note_finished(e, round, e.traj_index[g]);
         // the slot takes the next unplayed game of the round, if any
         bool seated = false;
         while (!seated) {
@@ -1071,7 +1081,7 @@ static void launch_tree_step_t(hipStream_t st, const EngineDev &e, const SearchD
                                const RoundDev *turnover, size_t lds, const GameSpan &span) {
     const int blocks = cdiv(span.end - span.first, kStepGames), threads = kStepGames * 64;
     if (blocks <= 0) return;
-    const RoundDev none = {nullptr, nullptr, nullptr, 0, 0};
+    const RoundDev none = {nullptr, nullptr, nullptr, 0, 0, 1, 1, nullptr};
     const bool cache = (p.flags & NNB_FLAG_EVAL_CACHE) && e.cache;
     if (turnover) {
         if (cache) tree_step_kernel<AZ, HEADS, true, true><<<blocks, threads, lds, st>>>(e, p, parity, heads, *turnover, span);
@@ -1131,7 +1141,7 @@ void launch_dirichlet_noise(hipStream_t st, int n, u64 seed, const int32_t *game
 
 void launch_readout(hipStream_t st, const EngineDev &e, const SearchDev &p, int32_t *visits_out,
                     int8_t *action_out, double *root_value_out, const RoundDev *round) {
-    RoundDev none = {nullptr, nullptr, nullptr, 0, 0};
+    RoundDev none = {nullptr, nullptr, nullptr, 0, 0, 1, 1, nullptr};
     readout_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, p, visits_out, action_out, root_value_out,
                                                          round ? *round : none, round != nullptr);
 }

@@ -255,6 +255,47 @@ class Engine:
                                               C.byref(stats)), "nnb_selfplay_round")
         return traj, stats.as_dict()
 
+    def selfplay_stream(self, min_finished: int, params: Optional[SearchParams] = None, restart: bool = False,
+                        first_game_id: int = 0, start_boards=None, start_players=None, ring_len: int = 0):
+        """Self-play as an endless stream of games on all max_games slots (nnb_selfplay_stream): returns once
+        `min_finished` more games have finished, with the games in flight left seated for the next call.
+        restart=True seats a fresh stream (game j has id first_game_id + j and starts from start position
+        j % len(start_boards), or the empty board); the ring of records it allocates holds `ring_len`
+        (default 8 x max_games) records.  Returns (records of the games finished in this call, in completion
+        order: device uint8 [f, 1376], a copy; stats of this call)."""
+        if restart:
+            if params is None:
+                raise ValueError("restart needs params")
+            n_ring = int(ring_len) if ring_len else 8 * self.max_games
+            self._ring = torch.empty((n_ring, TRAJECTORY_BYTES), dtype=torch.uint8, device=self.device)
+            self._finished_ring = torch.zeros(n_ring, dtype=torch.int32, device=self.device)
+            self._stream_starts = (None, None)
+            n_starts = 0
+            if start_boards is not None:
+                sb = self._dev(start_boards if isinstance(start_boards, torch.Tensor)
+                               else np.asarray(start_boards, dtype=np.uint64), torch.int64).reshape(-1, 2)
+                sp = self._dev(start_players if isinstance(start_players, torch.Tensor)
+                               else np.asarray(start_players, dtype=np.int8), torch.int8)
+                if sb.shape[0] != sp.shape[0] or sb.shape[0] < 1:
+                    raise ValueError("start boards and players must have the same, positive number of rows")
+                self._stream_starts = (sb, sp)
+                n_starts = sb.shape[0]
+            self._stream_n_starts = n_starts
+        elif getattr(self, "_ring", None) is None:
+            raise NnbError("no stream of games has been started on this engine: call with restart=True")
+        sb, sp = self._stream_starts
+        stats = RoundStats()
+        with torch.cuda.device(self.device):
+            check(self.lib.nnb_selfplay_stream(self.handle, self._stream(), C.byref(params) if params is not None else None,
+                                               int(bool(restart)), int(first_game_id), int(min_finished), _ptr(sb), _ptr(sp),
+                                               self._stream_n_starts, _ptr(self._ring), _ptr(self._finished_ring),
+                                               self._ring.shape[0], C.byref(stats)), "nnb_selfplay_stream")
+        st = stats.as_dict()
+        n_ring = self._ring.shape[0]
+        order = torch.arange(st["finished_total"] - st["games"], st["finished_total"], device=self.device) % n_ring
+        records = self._ring[self._finished_ring[order].long()]
+        return records, st
+
     def dirichlet_noise(self, seed: int, game_ids, move_indices, legal_masks, alpha: float) -> np.ndarray:
         """The root noise the engine draws for (seed, game id, move index); float32 [n,7]."""
         gi = self._dev(np.asarray(game_ids, dtype=np.int32), torch.int32)

@@ -173,6 +173,7 @@ typedef struct nnb_round_stats {
     int64_t cache_hits;          /* simulations answered by the evaluation cache    */
     int64_t chains;              /* tree step -> forward pass chains a lock-step round was split in (1, or 2
                                     halves on two streams): kernel launches per class = steps * chains      */
+    int64_t finished_total;      /* nnb_selfplay_stream: games finished since the stream was (re)started    */
 } nnb_round_stats;
 
 /* ---- library ----------------------------------------------------------- */
@@ -313,6 +314,29 @@ int nnb_selfplay_round(nnb_engine *engine, void *stream, const nnb_search_params
                        int32_t n_games, int32_t first_game_id,
                        const uint64_t *start_colour_boards, const int8_t *start_players,
                        nnb_trajectory *trajectories_out, nnb_round_stats *stats_out);
+
+/* Self-play as an endless stream of games: what the training loop's repeated self_play calls
+ * (train_alpha_zero.py:33-55, called once per iteration from :57-119) amount to when no iteration waits
+ * for the longest game of the one before.  All max_games slots stay occupied: game j = 0, 1, 2, ... has
+ * game_id = first_game_id + j, starts from start position j % n_starts (the empty board when
+ * start_colour_boards is NULL) and is recorded in record_ring[j % ring_len]; a slot whose game ends takes
+ * the next j.  What a game plays depends on its id and start position only, so record j equals what
+ * nnb_selfplay_round writes for the same id and start position, byte for byte.
+ * restart != 0 seats games 0 .. max_games-1 (and keeps the pointer arguments, which must stay valid,
+ * for the calls that follow); restart == 0 carries on with the games seated by the previous call
+ * (params may be NULL or must equal the first call's; the pointer arguments are ignored).  Either way
+ * the call returns once at least min_finished more games have finished; games in flight stay seated.
+ * finished_ring (device, ring_len ints, may be NULL): entry k % ring_len = index into record_ring of the
+ * k-th game to finish since the restart; with stats_out->finished_total = F after the call and
+ * stats_out->games = f, this call's records are entries F-f .. F-1.  ring_len >= 4 * max_games; a record is
+ * reused ring_len games later, so the caller copies finished records out between calls (a game that lasts
+ * while ring_len - max_games later games are seated would be overwritten; no legal game does at 4 x).
+ * stats_out counts the work of this call only.  Any other call that searches or runs the network on this
+ * engine ends the stream (the next call needs restart != 0).  Synchronous. */
+int nnb_selfplay_stream(nnb_engine *engine, void *stream, const nnb_search_params *params, int32_t restart,
+                        int32_t first_game_id, int32_t min_finished, const uint64_t *start_colour_boards,
+                        const int8_t *start_players, int32_t n_starts, nnb_trajectory *record_ring,
+                        int32_t *finished_ring, int32_t ring_len, nnb_round_stats *stats_out);
 
 /* The Dirichlet(alpha) root noise the engine draws for (seed, game id, move index) over the
  * legal columns of each row: out [n,7], zero on illegal columns, rows sum to 1.  Exposed so a

@@ -1,0 +1,104 @@
+"""Self-play as an endless stream of games (nnb_selfplay_stream): games stay seated between calls, every
+slot stays occupied, and what a game plays depends on its id and start position only - so each record
+must equal, byte for byte, the record nnb_selfplay_round writes for the same id and start position
+(that round is held to the oracle and to the reference's captured games in the other GPU tests)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (torch.cuda.is_available() is False)")
+    return torch
+
+
+def _stream_records(eng, params, calls, per_call, **kw):
+    from alphazero_amd.engine import trajectories_to_numpy
+    recs, totals = [], {"games": 0, "sims": 0, "plies": 0}
+    for i in range(calls):
+        r, st = eng.selfplay_stream(per_call, params if i == 0 else None, restart=(i == 0), **kw)
+        assert st["games"] >= per_call and r.shape[0] == st["games"]
+        recs.append(trajectories_to_numpy(r).copy())
+        for k in totals:
+            totals[k] += st[k]
+        assert st["finished_total"] == totals["games"]
+    return np.concatenate(recs), totals
+
+
+@pytest.mark.parametrize("evaluator,mode", [("hash_q8", "compat"), ("hash_f32", "az")])
+def test_stream_records_equal_round_records(gpu, evaluator, mode):
+    from alphazero_amd.engine import Engine, trajectories_to_numpy
+    from alphazero_amd.selfplay import random_openings
+    slots, sims, n_starts = 48, 40, 100
+    eng = Engine(max_games=slots, max_sims=sims)
+    try:
+        extra = dict(dirichlet_alpha=0.3, dirichlet_eps=0.25, seed=5) if mode == "az" else {}
+        params = eng.params(sims, 1.4, evaluator=evaluator, mode=mode, lockstep=True, **extra)
+        sb, sp = random_openings(eng, n_starts, 5, seed=3)
+        rec, totals = _stream_records(eng, params, calls=4, per_call=70, first_game_id=1000, start_boards=sb, start_players=sp)
+        ids = rec["game_id"] - 1000
+        assert len(set(ids.tolist())) == len(ids) and ids.min() >= 0            # every game listed once
+        assert (rec["result"] != 2).all()
+        n = int(ids.max()) + 1
+        assert n > n_starts                                                       # start positions wrapped around
+        # the same games as one plain round
+        sel = np.arange(n) % n_starts
+        traj, _ = eng.selfplay_round(n, params, first_game_id=1000, start_boards=sb[sel], start_players=sp[sel])
+        ref = trajectories_to_numpy(traj)
+        assert rec.tobytes() == ref[ids].tobytes()
+        assert totals["plies"] >= int(rec["length"].sum())                        # games in flight have played plies too
+        # the plain round ended the stream
+        with pytest.raises(Exception, match="restart"):
+            eng.selfplay_stream(1)
+    finally:
+        eng.close()
+
+
+def test_stream_with_the_network_two_chains(gpu):
+    """Network evaluator on enough slots for the two-stream split; the ring wraps (ring_len = 4 x slots)."""
+    from alphazero_amd.engine import Engine, trajectories_to_numpy
+    from alphazero_amd.network import seeded_state_dict
+    from alphazero_amd.selfplay import random_openings
+    slots, sims = 64, 24
+    eng = Engine(max_games=slots, max_sims=sims)
+    try:
+        eng.load_state_dict(seeded_state_dict(0))
+        params = eng.params(sims, 1.4, evaluator="net", mode="compat", two_streams=True)
+        sb, sp = random_openings(eng, 512, 6, seed=11)
+        rec, totals = _stream_records(eng, params, calls=6, per_call=60, start_boards=sb, start_players=sp,
+                                      ring_len=4 * slots)
+        assert totals["games"] > 4 * slots                                        # the ring was reused
+        ids = rec["game_id"]
+        assert len(set(ids.tolist())) == len(ids)
+        n = int(ids.max()) + 1
+        sel = np.arange(n) % 512
+        traj, st = eng.selfplay_round(n, params, first_game_id=0, start_boards=sb[sel], start_players=sp[sel])
+        ref = trajectories_to_numpy(traj)
+        assert rec.tobytes() == ref[ids].tobytes()
+    finally:
+        eng.close()
+
+
+def test_stream_argument_checks(gpu):
+    from alphazero_amd.engine import Engine
+    eng = Engine(max_games=16, max_sims=8)
+    try:
+        p = eng.params(8, 1.4, evaluator="hash_q8", lockstep=True)
+        with pytest.raises(Exception, match="restart"):
+            eng.selfplay_stream(1)
+        with pytest.raises(Exception, match="ring"):
+            eng.selfplay_stream(1, p, restart=True, ring_len=17)
+        with pytest.raises(Exception, match="LOCKSTEP"):
+            eng.selfplay_stream(1, eng.params(8, 1.4, evaluator="hash_q8"), restart=True)
+        r, st = eng.selfplay_stream(0, p, restart=True)
+        assert st["games"] == 0 and r.shape[0] == 0
+        r, st = eng.selfplay_stream(5)
+        assert st["games"] >= 5
+        with pytest.raises(Exception, match="differ"):
+            eng.selfplay_stream(1, eng.params(8, 2.0, evaluator="hash_q8", lockstep=True))
+    finally:
+        eng.close()

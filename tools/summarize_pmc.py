@@ -1,6 +1,7 @@
 """Folds rocprofv3 output into the per-kernel summaries kept under profiles/.
 
   python tools/summarize_pmc.py --fetch <dir> --write <dir> --stats <dir> --dtype f16 --tag r01_f16
+      [--sq <dir>] [--l2 <dir>] [--outdir <dir>] [--bench-log <file>]
 
 <dir>s are rocprofv3 -d output directories: --fetch from a `--pmc FETCH_SIZE` pass, --write from a
 `--pmc WRITE_SIZE` pass (each counter needs a pass of its own), --stats from `--kernel-trace --stats`.
@@ -30,7 +31,7 @@ def kernel_class(name: str):
         return "conv2" if any(t in name for t in ("<7, 8", "<7,8", "ILi7ELi8E")) else "conv4"
     if "conv_mid" in name:
         return "conv2" if any(t in name for t in ("<7, 8", "<7,8", "ILi7ELi8E")) else "conv4"
-    if "fc_f16_kernel" in name or "fc_kernel" in name: return "fc"
+    if "fc_f16_kernel" in name or "fc_kernel" in name or "fc_split_kernel" in name: return "fc"
     if "heads" in name: return "heads"
     return None
 
@@ -63,13 +64,28 @@ def all_counters_per_class(d):
     return {k: {c: tot[k][c] / cnt[k][c] for c in tot[k]} for k in tot}, {k: max(cnt[k].values()) for k in cnt}
 
 
+OUTDIR = os.path.join(ROOT, "profiles")
+
+
+def write_l2_summary(d, tag):
+    """Per-launch averages of a TCC_HIT_sum / TCC_MISS_sum pass and the L2 hit rate they give."""
+    avg, launches = all_counters_per_class(d)
+    path = os.path.join(OUTDIR, f"{tag}_pmc_l2_summary.csv")
+    with open(path, "w") as fh:
+        fh.write("kernel,launches,TCC_HIT_sum,TCC_MISS_sum,l2_hit_rate\n")
+        for k in sorted(avg):
+            h, m = avg[k].get("TCC_HIT_sum", 0.0), avg[k].get("TCC_MISS_sum", 0.0)
+            fh.write(f"{k},{launches[k]},{h:.1f},{m:.1f},{h / (h + m) if h + m else 0.0:.4f}\n")
+    print(open(path).read())
+
+
 def write_sq_summary(d, tag):
     """Per-launch averages of an SQ/GRBM pass.  GRBM_GUI_ACTIVE is summed over the 8 XCDs, so
     cycles per launch = GRBM_GUI_ACTIVE / 8; MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES (one count
     per SIMD-cycle an MFMA occupies) / (1024 SIMDs x cycles per launch)."""
     avg, launches = all_counters_per_class(d)
     names = sorted({c for k in avg for c in avg[k]})
-    path = os.path.join(ROOT, "profiles", f"{tag}_pmc_sq_summary.csv")
+    path = os.path.join(OUTDIR, f"{tag}_pmc_sq_summary.csv")
     with open(path, "w") as fh:
         fh.write("kernel,launches," + ",".join(names) + ",cycles_per_launch,mfma_util\n")
         for k in sorted(avg):
@@ -82,6 +98,9 @@ def write_sq_summary(d, tag):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sq", help="directory of an SQ/GRBM counter pass (optional)")
+    ap.add_argument("--l2", help="directory of a TCC_HIT_sum TCC_MISS_sum pass (optional)")
+    ap.add_argument("--outdir", help="where the summaries go (default: profiles/)")
+    ap.add_argument("--bench-log", help="stdout of the profiled bench.py run: its JSON line gives leaves per launch")
     ap.add_argument("--fetch", required=True)
     ap.add_argument("--write", required=True)
     ap.add_argument("--stats")
@@ -89,8 +108,14 @@ def main():
     ap.add_argument("--tag", required=True)
     ap.add_argument("--command", default="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline")
     a = ap.parse_args()
+    global OUTDIR
+    if a.outdir:
+        OUTDIR = a.outdir
+    os.makedirs(OUTDIR, exist_ok=True)
     if a.sq:
         write_sq_summary(a.sq, a.tag)
+    if a.l2:
+        write_l2_summary(a.l2, a.tag)
     fetch, write = counter_per_class(a.fetch, "FETCH_SIZE"), counter_per_class(a.write, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
@@ -100,13 +125,19 @@ def main():
     out = {"source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over `{a.command}`",
            "correction": "gfx950: read bytes = 2 x FETCH_SIZE for 16-B-per-lane coalesced reads; WRITE_SIZE as reported",
            "unit": "bytes per launch", "dtype": a.dtype, "kernels": kernels}
-    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    with open(os.path.join(ROOT, "profiles", f"{a.tag}_traffic.json"), "w") as fh:
+    if a.bench_log:
+        for line in open(a.bench_log):
+            if line.startswith("{"):
+                bj = json.loads(line)
+                out["leaves_per_launch"] = bj["roofline"]["leaves_per_launch"]
+                with open(os.path.join(OUTDIR, f"{a.tag}_bench_under_rocprof.json"), "w") as fh:
+                    json.dump(bj, fh, indent=1)
+    with open(os.path.join(OUTDIR, f"{a.tag}_traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     if a.stats:
         st = glob.glob(os.path.join(a.stats, "**", "*kernel_stats.csv"), recursive=True)
         if st:
-            shutil.copy(st[0], os.path.join(ROOT, "profiles", f"{a.tag}_kernel_stats.csv"))
+            shutil.copy(st[0], os.path.join(OUTDIR, f"{a.tag}_kernel_stats.csv"))
     print(json.dumps(kernels, indent=1))
 
 
