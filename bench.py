@@ -2,14 +2,19 @@
 """Self-play throughput benchmark: 4096 concurrent games x 200 sims/move per GPU (one GPU at N=1,
 the same per-GPU share on each of N GPUs at N>1).
 
-One "step" = one self-play round: every rank plays GAMES_PER_STEP Connect Four games to the end,
-GAMES_PER_GPU of them at a time (a finished game's slot takes the round's next game), with the
-reference's search (200 simulations per move, same searcher on both sides, random-init seed-0
-Connect4Net in float32-faithful arithmetic as the leaf evaluator, all leaves of a simulation round
-batched into one forward pass), then the finished trajectories are all-gathered over RCCL.
+Every rank plays an endless stream of Connect Four self-play games on GAMES_PER_GPU slots (a finished
+game's slot takes the next game, so the leaf batch stays full) with the reference's search (200
+simulations per move, same searcher on both sides, random-init seed-0 Connect4Net in float32-faithful
+arithmetic as the leaf evaluator, all leaves of a simulation round batched into one forward pass).
+One "step" = wait until GAMES_PER_GPU more games have finished on this rank, then all-gather the step's
+finished trajectories over RCCL.  `value` = games finished inside the timed region / its duration: games in
+flight when the region starts were begun by the warm-up steps, as those in flight at its end are finished
+by whatever follows - the steady state of a self-play service.  `sims_per_s` counts the searches completed
+inside the region, whichever game they belong to.  (A plain round of games played until the last one has
+ended is reported as single_round_*.)
 The reference's search is deterministic, so its games from the empty board are all the same game;
-the timed games therefore start from distinct positions (OPENING_PLIES uniformly random legal moves).
-Weak scaling: per-GPU work is fixed.
+the timed games therefore start from OPENING_PLIES uniformly random legal moves (16384 drawn start
+positions per rank, at most 7^4 of them distinct).  Weak scaling: per-GPU work is fixed.
 
     python bench.py --gpus 1 --steps 1 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -19,7 +24,10 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     : the dominant kernel's algorithmic FLOP rate (each float32 product counted once) against
                  the MI355X dense peak of the matrix instruction it issues (half inputs: 2.5 PFLOP/s;
                  exact f32: 157.3 TFLOP/s); its duration is sampled with HIP events on the stream the
-                 kernel is launched on, inside the timed region (16 launches of every 64 lock-step rounds);
+                 kernel is launched on, inside the timed region (16 launches of every 64 lock-step rounds).
+                 With two chains on two streams (concurrent_chains = 2) a launch shares the chip with the other
+                 chain's kernel, so region_frac gives the network's algorithmic FLOPs of the whole timed region
+                 over its duration, and roofline_one_chain the same kernel with the chip to itself;
   cpu_baseline : the CPU restatement of the reference path (oracle/ref_port.py: numpy board,
                  one game at a time, batch-1 torch-CPU forward) timed on this box's host cores
                  on a bounded sample, at 200 and at 100 simulations per move (rank 0, N=1 only);
@@ -40,7 +48,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GAMES_PER_GPU = 4096          # concurrent games (slots)
-GAMES_PER_STEP = 16384        # games per self-play round and GPU
 OPENING_PLIES = 4
 SIMS = 200
 C_PUCT = 1.4
@@ -120,7 +127,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--games", type=int, default=GAMES_PER_GPU, help="concurrent games (slots) per GPU")
     ap.add_argument("--games-per-step", type=int, default=0,
-                    help=f"games per round and GPU (default {GAMES_PER_STEP // GAMES_PER_GPU} x --games)")
+                    help="finished games per GPU a step waits for (default: --games)")
     ap.add_argument("--sims", type=int, default=SIMS)
     ap.add_argument("--precision", choices=["f16", "f32", "f32s"], default="f32s",
                     help="arithmetic of the network's conv / linear layers (all accumulate in f32); f32s and f32 are\n"
@@ -171,26 +178,44 @@ def main():
             os.close(saved_stdout)
 
     G = args.games                                             # slots
-    NG = args.games_per_step if args.games_per_step > 0 else G * (GAMES_PER_STEP // GAMES_PER_GPU)
+    NG = args.games_per_step if args.games_per_step > 0 else G # games a step waits for
+    PAD = max(G // 8, 64)                                      # a step ends on a 64-round boundary: a few games more finish
     extras = world == 1 and not args.no_extra_lines
     engine = Engine(max_games=G, max_sims=args.sims, device=device, precision=args.precision,
                     eval_cache_slots=2048 if extras else 0)
     engine.load_state_dict(seeded_state_dict(0))
     params = engine.params(args.sims, C_PUCT, evaluator="net", mode="compat", one_stream=args.one_stream)
-    traj = torch.empty((NG, TRAJECTORY_BYTES), dtype=torch.uint8, device=device)
-    replay = torch.empty((world * NG, TRAJECTORY_BYTES), dtype=torch.uint8, device=device) if use_dist else traj
+    # what every rank contributes to the replay buffer per step: the step's finished records (NG + PAD rows, the
+    # rows past the count repeat the last record) - fixed size, so one all-gather moves them
+    local = torch.empty((NG + PAD, TRAJECTORY_BYTES), dtype=torch.uint8, device=device)
+    replay = torch.empty((world * (NG + PAD), TRAJECTORY_BYTES), dtype=torch.uint8, device=device) if use_dist else local
 
-    def openings(step_idx: int):
-        if args.opening_plies <= 0:
-            return None, None
-        b, p = random_openings(engine, NG, args.opening_plies, seed=1234 + step_idx * world + rank)
-        return (torch.from_numpy(b.view("int64")).to(device), torch.from_numpy(p).to(device))
+    # start positions are inputs: resident in HBM before the timed region starts
+    N_STARTS = 16384
+    starts = (None, None)
+    if args.opening_plies > 0:
+        b, p = random_openings(engine, N_STARTS, args.opening_plies, seed=1234 + rank)
+        starts = (torch.from_numpy(b.view("int64")).to(device), torch.from_numpy(p).to(device))
 
-    def one_round(eng, prm, step_idx: int, start, n_games=NG, out=traj):
-        _, stats = eng.selfplay_round(n_games, prm, first_game_id=(step_idx * world + rank) * NG, out=out[:n_games],
-                                      start_boards=start[0], start_players=start[1])
-        if use_dist and eng is engine and n_games == NG:
-            dist.all_gather_into_tensor(replay, traj)      # RCCL: trajectories into every rank's buffer
+    state = {"started": False}
+
+    def one_step(eng=engine, prm=params, key="started", gather=True):
+        """Waits for NG more finished games of the endless stream of self-play games on the G slots."""
+        first = not state.get(key, False)
+        state[key] = True
+        rec, stats = eng.selfplay_stream(NG, prm if first else None, restart=first, first_game_id=rank << 24,
+                                         start_boards=starts[0], start_players=starts[1])
+        if gather:
+            n = min(rec.shape[0], NG + PAD)
+            local[:n] = rec[:n]
+            local[n:] = rec[n - 1]
+            if use_dist:
+                dist.all_gather_into_tensor(replay, local)     # RCCL: trajectories into every rank's buffer
+        return stats
+
+    def one_plain_round(eng, prm, n_games, start):
+        out = torch.empty((n_games, TRAJECTORY_BYTES), dtype=torch.uint8, device=device)
+        _, stats = eng.selfplay_round(n_games, prm, first_game_id=0, out=out, start_boards=start[0], start_players=start[1])
         return stats
 
     def fence():
@@ -199,54 +224,74 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    # start positions are inputs: resident in HBM before the timed region starts
-    starts = [openings(i) for i in range(args.warmup + args.steps)]
+    # The stream is seated before the timed region: the games in flight when it starts were begun by the warm-up
+    # steps, as those in flight when it ends are left to the steps that would follow (steady state).  With
+    # --warmup 0 the timed region includes seating all G games at once and their common first moves.
     for w in range(args.warmup):
-        one_round(engine, params, w, starts[w])
+        one_step()
     engine.profile(True)
     fence()
     t0 = time.perf_counter()
     totals = {}
     for k in range(args.steps):
-        st = one_round(engine, params, args.warmup + k, starts[args.warmup + k])
+        st = one_step()
         for key, v in st.items():
-            totals[key] = v if key == "chains" else totals.get(key, 0) + v
+            totals[key] = v if key in ("chains", "finished_total") else totals.get(key, 0) + v
     fence()
     elapsed = time.perf_counter() - t0
+    elapsed_rank0 = elapsed
     prof = engine.profile_report()
     engine.profile(False)
 
-    def timed_extra(eng, prm, start, n_games, note):
+    def timed(fn, note):
         fence()
         c0 = time.perf_counter()
-        st = one_round(eng, prm, 0, start, n_games=n_games)
+        st = fn()
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - c0
         return {"games_per_s": st["games"] / dt, "sims_per_s": st["sims"] / dt, "seconds": dt, "games": st["games"],
                 "plies_per_game": st["plies"] / max(st["games"], 1), "net_leaves": st["net_leaves"],
                 "cache_hits": st["cache_hits"], "note": note}
 
-    # Extra rounds on one GPU, each timed on its own and none part of `value`.
+    # Extra measurements on one GPU, each timed on its own and none part of `value`.
     extra = {}
+    prof_one = None
+    if extras and totals.get("chains", 1) > 1:
+        # The timed region runs two tree step -> forward pass chains on two streams, so a kernel there shares the
+        # chip with the other chain's kernel and its launch takes longer than its work does.  One more step with
+        # all games in one chain times every kernel with the chip to itself.
+        p1 = engine.params(args.sims, C_PUCT, evaluator="net", mode="compat", one_stream=True)
+        one_step(engine, p1, "one_chain", gather=False)
+        engine.profile(True)
+        st1 = one_step(engine, p1, "one_chain", gather=False)
+        prof_one = (engine.profile_report(), st1)
+        engine.profile(False)
     if extras:
-        last = starts[-1]
-        extra["single_round_identical_games"] = timed_extra(
-            engine, params, (None, None), G,
-            f"{G} games from the empty board in one round with no refill: the reference's search is deterministic, "
-            "so this is one game played on every slot (best-case batch fill)")
+        extra["single_round_identical_games"] = timed(
+            lambda: one_plain_round(engine, params, G, (None, None)),
+            f"one plain round (nnb_selfplay_round) of {G} games from the empty board, no refill: the reference's search "
+            "is deterministic, so this is one game played on every slot, all slots in step (best-case batch fill, "
+            "the round-1 workload)")
+        extra["single_round_distinct_games"] = timed(
+            lambda: one_plain_round(engine, params, 4 * G, (starts[0], starts[1])),
+            f"one plain round of {4 * G} games from the timed region's start positions on {G} slots, played until the "
+            "last game has ended (the slots drain at the end of the round)")
         cparams = engine.params(args.sims, C_PUCT, evaluator="net", mode="compat", eval_cache=True)
-        extra["with_eval_cache"] = timed_extra(
-            engine, cparams, last, NG,
-            "the headline games with the per-game evaluation cache: a leaf whose position its game has already "
-            "evaluated is not sent to the network again; same trajectories; the reference evaluates every leaf")
+        for _ in range(3):
+            one_step(engine, cparams, "cache", gather=False)
+        extra["with_eval_cache"] = timed(
+            lambda: one_step(engine, cparams, "cache", gather=False),
+            "one more step of the same stream with the per-game evaluation cache: a leaf whose position its game has "
+            "already evaluated is not sent to the network again; same trajectories; the reference evaluates every leaf")
         if args.precision != "f16":
             e16 = Engine(max_games=G, max_sims=args.sims, device=device, precision="f16")
             e16.load_state_dict(seeded_state_dict(0))
             p16 = e16.params(args.sims, C_PUCT, evaluator="net", mode="compat")
-            one_round(e16, p16, 0, last)
-            extra["f16_inputs"] = timed_extra(
-                e16, p16, last, NG,
-                "the headline workload with the inputs of every product rounded to half precision (f32 accumulate): "
+            for _ in range(3):
+                one_step(e16, p16, "f16", gather=False)
+            extra["f16_inputs"] = timed(
+                lambda: one_step(e16, p16, "f16", gather=False),
+                "one step of the same stream with the inputs of every product rounded to half precision (f32 accumulate): "
                 "narrower than the reference's float32, so not comparable with `value`")
             e16.close()
 
@@ -255,7 +300,7 @@ def main():
     if use_dist:
         fence()
         g0 = time.perf_counter()
-        dist.all_gather_into_tensor(replay, traj)
+        dist.all_gather_into_tensor(replay, local)
         torch.cuda.synchronize(device)
         gather_ms = (time.perf_counter() - g0) * 1e3
 
@@ -282,7 +327,7 @@ def main():
         achieved = (leaves_per_launch * FLOP_PER_LEAF[dom]) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         net_ms = sum(prof[k]["avg_ms"] for k in FLOP_PER_LEAF)
         net_tflops = (leaves_per_launch * sum(FLOP_PER_LEAF.values())) / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0
-        standard = G == GAMES_PER_GPU and args.sims == SIMS and NG == GAMES_PER_STEP and args.opening_plies == OPENING_PLIES
+        standard = G == GAMES_PER_GPU and args.sims == SIMS and args.opening_plies == OPENING_PLIES
         traffic, traffic_src = committed_traffic(args.precision, dom, leaves_per_launch) if standard else (None, None)
         tree_traffic, _ = committed_traffic(args.precision, "tree_step", leaves_per_launch) if standard else (None, None)
         plies_per_game = job["plies"] / max(games, 1)
@@ -309,9 +354,10 @@ def main():
                                      if args.opening_plies else "games from the empty board")
                     + ", random-init Connect4Net (torch.manual_seed(0))",
             "config": {"workload": f"{G} concurrent games per GPU x {args.sims} sims/move, batched leaf inference, "
-                                   f"reference search rule (compat), {NG} games per round and GPU played to the end "
-                                   "(a finished game's slot takes the next game)",
-                       "games_per_gpu": G, "games_per_step_per_gpu": NG, "sims_per_move": args.sims, "c_puct": C_PUCT,
+                                   "reference search rule (compat), an endless stream of self-play games (a finished "
+                                   f"game's slot takes the next game); a step waits for {NG} more finished games per GPU; "
+                                   "games counted = games finished inside the timed region",
+                       "games_per_gpu": G, "finished_games_per_step_per_gpu": NG, "sims_per_move": args.sims, "c_puct": C_PUCT,
                        "opening_plies": args.opening_plies,
                        "parallelism": f"games sharded over {world} GPU(s), no collective inside the search; "
                                       "one all-gather of trajectories per round"},
@@ -321,7 +367,7 @@ def main():
                       "leaf_batch_fill": job["net_leaves"] / max(job["steps"] * G, 1),
                       "lockstep_rounds": job["steps"], "launch_chains_per_round": chains,
                       "allgather_ms": gather_ms,
-                      "allgather_bytes": world * NG * TRAJECTORY_BYTES if use_dist else 0},
+                      "allgather_bytes": world * (NG + PAD) * TRAJECTORY_BYTES if use_dist else 0},
             "kernel_ms": {k: round(v["avg_ms"], 4) for k, v in prof.items()},
             "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.precision],
                          "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": traffic,
@@ -329,12 +375,30 @@ def main():
                          "flop_per_leaf": FLOP_PER_LEAF[dom], "leaves_per_launch": leaves_per_launch,
                          "avg_launch_ms": avg_ms, "whole_net_tflops": net_tflops,
                          "mfma_per_product": mfma_per_product,
-                         "issued_frac": achieved * mfma_per_product / PEAK_TFLOPS[args.precision]},
+                         "issued_frac": achieved * mfma_per_product / PEAK_TFLOPS[args.precision],
+                         "concurrent_chains": chains,
+                         "region_net_tflops": totals["net_leaves"] * sum(FLOP_PER_LEAF.values()) / (elapsed_rank0 * 1e12),
+                         "region_frac": totals["net_leaves"] * sum(FLOP_PER_LEAF.values()) / (elapsed_rank0 * 1e12)
+                                        / PEAK_TFLOPS[args.precision]},
             "roofline_tree": {"kernel": "tree_step", "bound": "hbm", "achieved": tree_gbs, "peak": PEAK_HBM_GBS,
                               "unit": "GB/s", "frac": tree_gbs / PEAK_HBM_GBS, "traffic": tree_traffic,
                               "bytes_per_sim": tree_bytes_per_sim, "sims_per_launch": sims_per_launch,
                               "avg_launch_ms": tree_ms},
         }
+        if prof_one is not None:
+            p1, st1 = prof_one
+            lpl = st1["net_leaves"] / max(st1["steps"], 1)
+            ms = p1[dom]["avg_ms"]
+            ach = lpl * FLOP_PER_LEAF[dom] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            tr, src = committed_traffic(args.precision, dom, lpl) if standard else (None, None)
+            out["roofline_one_chain"] = {
+                "kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+                "frac": ach / PEAK_TFLOPS[args.precision], "traffic": tr, "traffic_source": src,
+                "leaves_per_launch": lpl, "avg_launch_ms": ms,
+                "issued_frac": ach * mfma_per_product / PEAK_TFLOPS[args.precision],
+                "kernel_ms": {k: round(v["avg_ms"], 4) for k, v in p1.items()},
+                "note": "one more step outside the timed region with all games in one chain (bench.py --one-stream "
+                        "times the whole run that way): every kernel has the chip to itself"}
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.sims)
