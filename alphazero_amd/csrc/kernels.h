@@ -78,7 +78,10 @@ struct NetBuffers {            // activations, channels-last float32
     float *act2_inv_b1, *act3_inv_b1;
     int max_rows;              // G
 };
-enum NetStage { NET_CONV0 = 0, NET_CONV2 = 1, NET_CONV4 = 2, NET_FC = 3, NET_HEADS = 4 };
+enum NetStage { NET_CONV0 = 0, NET_CONV2 = 1, NET_CONV4 = 2, NET_FC = 3, NET_HEADS = 4,
+                // float32-faithful path only: NET_CONV0 + NET_CONV2 + NET_CONV4 as one launch (the activations between the
+                // two 128->128 layers stay in LDS), and the same with those activations also copied out
+                NET_CONV_PAIR = 5, NET_CONV_PAIR_MID = 6 };
 
 HeadsDev heads_input_f32(const NetWeights &w, const NetBuffers &b);
 HeadsDev heads_input_f16(const NetWeights &w, const NetBuffers &b);

@@ -209,20 +209,22 @@ __device__ __forceinline__ void conv_split_finish(f32x16 (&acc)[IH + 1], const f
     });
 }
 
-// Step 2: quantise with the board's scale and put hi / lo into the output tile in LDS.  A lane swaps its
-// (hi, lo) pair with the neighbouring channel's lane (same cell) so that the even lane stores both hi
-// halves and the odd lane both lo halves as one 32-bit word each.
-template <int IH, int IW, int NB>
+// Step 2: quantise with the board's scale and put hi / lo into LDS: output cell (board j, row t, column c)
+// goes to position LEADO + j*BSO + t*RSO + c.  (BSO, RSO, LEADO) = (cells per board, cells per row, 0) is the
+// dense output tile that is copied to memory; (conv_board_stride, OW + 2, 2) is the input image of the next
+// 4x4 layer.  A lane swaps its (hi, lo) pair with the neighbouring channel's lane (same cell) so that the
+// even lane stores both hi halves and the odd lane both lo halves as one 32-bit word each.
+template <int IH, int IW, int NB, int BSO = (IH + 1) * (IW + 1), int RSO = IW + 1, int LEADO = 0>
 __device__ __forceinline__ void conv_split_store(const f32x16 (&acc)[IH + 1], const float (&sout)[NB],
                                                  unsigned *ldsw, int ch, int odd, int h) {
-    constexpr int OH = IH + 1, OW = IW + 1, OP = OH * OW, RC = NB * OW;
+    constexpr int OH = IH + 1, OW = IW + 1, RC = NB * OW;
     const int col = (ch >> 1) + (odd ? SP_LO / 4 : 0);           // dword inside a position
     const unsigned psel = odd ? 0x03020706u : 0x05040100u;       // v_perm_b32 byte selector, bytes 4-7 = first operand
     static_for<16>([&](auto Rr) __attribute__((always_inline)) {
         constexpr int r = decltype(Rr)::value;
         constexpr int c0 = sigma((r & 3) + 8 * (r >> 2)), c1 = sigma((r & 3) + 8 * (r >> 2) + 4);
         constexpr int j0 = c0 < RC ? c0 / OW : NB - 1, j1 = c1 < RC ? c1 / OW : NB - 1;
-        constexpr int R0 = j0 * OP + c0 % OW, R1 = j1 * OP + c1 % OW;      // tile position of output row 0
+        constexpr int R0 = LEADO + j0 * BSO + c0 % OW, R1 = LEADO + j1 * BSO + c1 % OW;   // position of output row 0
         const bool live = h ? c1 < RC : c0 < RC;
         const float sc_out = h ? sout[j1] : sout[j0];
         unsigned *dst = ldsw + (h ? R1 : R0) * (SP_PB / 4) + col;
@@ -237,7 +239,7 @@ __device__ __forceinline__ void conv_split_store(const f32x16 (&acc)[IH + 1], co
                 const unsigned own = __builtin_bit_cast(unsigned, pr);
                 const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);   // lane ^ 1
                 // even lane: (own hi, other hi); odd lane: (other lo, own lo)
-                dst[t * OW * (SP_PB / 4)] = __builtin_amdgcn_perm(other, own, psel);
+                dst[t * RSO * (SP_PB / 4)] = __builtin_amdgcn_perm(other, own, psel);
             });
         }
     });
@@ -468,6 +470,246 @@ __global__ __launch_bounds__(256, 1) void conv_rows_split_kernel(const u32x4 *__
 }
 
 // ---------------------------------------------------------------------------
+// Both 128->128 layers in one launch (network.py:29-34 from the side boards to the second ReLU): the block
+// runs the first layer as conv_rows_split_kernel<7, 8, NB, .., true> does, but its epilogue writes the
+// quantised output straight into the LDS image the second layer reads (same hi / lo halves and per-board
+// scales as the two-launch form, so the results are the same bit for bit), and the second layer follows in
+// the same block.  The 7x8 -> 8x9 activations never exist in memory (147 MB written and read back per 4096
+// leaves otherwise), and the second layer's staging loop and the first layer's copy-out disappear.
+// WRITE_MID also copies those activations out (act2, act2_inv) for callers that want to look at them.
+// ---------------------------------------------------------------------------
+constexpr size_t conv_pair_lds_bytes(int nb) {
+    size_t a = conv_split_lds_bytes(7, 8, nb), b = conv_split_lds_bytes(8, 9, nb);
+    return a > b ? a : b;
+}
+
+template <int NB, int BRING, int ARING, bool WRITE_MID>
+__global__ __launch_bounds__(256, 1) void conv_pair_split_kernel(const u64 *__restrict__ side,
+                                                                 const u32x4 *__restrict__ w0h,
+                                                                 const u32x4 *__restrict__ w0l,
+                                                                 const float *__restrict__ b0,
+                                                                 const u32x4 *__restrict__ w2h,
+                                                                 const u32x4 *__restrict__ w2l,
+                                                                 const float *__restrict__ bias2,
+                                                                 const u32x4 *__restrict__ w4h,
+                                                                 const u32x4 *__restrict__ w4l,
+                                                                 const float *__restrict__ bias4,
+                                                                 const SplitScales *__restrict__ sc,
+                                                                 u32x4 *__restrict__ mid, float *__restrict__ mid_inv_scale,
+                                                                 u32x4 *__restrict__ out, float *__restrict__ out_inv_scale,
+                                                                 const int32_t *__restrict__ count_ptr, int n_fixed) {
+    constexpr int PB = SP_PB, LEAD = 2;
+    // first layer: 7x8 -> 8x9; second: 8x9 -> 9x10
+    constexpr int IH1 = 7, IW1 = 8, IP1 = IH1 * IW1, W21 = IW1 + 2, BS1 = conv_board_stride(IH1, IW1), NPOS1 = LEAD + NB * BS1 + 2;
+    constexpr int IH2 = 8, IW2 = 9, IP2 = IH2 * IW2, W22 = IW2 + 2, BS2 = conv_board_stride(IH2, IW2), NPOS2 = LEAD + NB * BS2 + 2;
+    constexpr int OH2 = IH2 + 1, OW2 = IW2 + 1, OP2 = OH2 * OW2;
+    static_assert(NB * OW2 <= 32, "one output row of all boards must fit one 32-row MFMA tile");
+    constexpr int R1 = (NPOS1 > NB * IP2 ? NPOS1 : NB * IP2), R2 = (NPOS2 > NB * OP2 ? NPOS2 : NB * OP2);
+    constexpr int REGION = (R1 > R2 ? R1 : R2) * PB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4 *lds = reinterpret_cast<u32x4 *>(smem_raw);
+    float *s_max = reinterpret_cast<float *>(smem_raw + REGION);     // [4 waves][NB]
+
+    const int count = batch_count_sp(count_ptr, n_fixed);
+    const int b0i = blockIdx.x * NB;
+    if (b0i >= count) return;
+    const int nb_valid = min(NB, count - b0i);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, nt = tid >> 6, m = lane & 31, h = lane >> 5;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    // ---- leaf encode + 2->128 layer into the first image (as conv_rows_split_kernel<.., true>) ----
+    for (int e = tid; e < NPOS1 * SP_RS; e += 256) lds[e] = zero4;
+    __syncthreads();
+    {
+        half8 bwh[2], bwl[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            bwh[pl] = as_half8(w0h[(nt * 32 + m) * 4 + 2 * pl + h]);
+            bwl[pl] = as_half8(w0l[(nt * 32 + m) * 4 + 2 * pl + h]);
+        }
+        const float bv_in = b0[nt * 32 + m];
+        const float inv_sw0 = sc->inv_sw0, sa1 = sc->sa1;
+        _Float16 *ldsh_in = reinterpret_cast<_Float16 *>(smem_raw);
+        for (int j = 0; j < nb_valid; ++j) {
+            const u64 planes[2] = {side[2 * (b0i + j)], side[2 * (b0i + j) + 1]};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int pos = mt * 32 + m, oh = pos >> 3, ow = pos & 7;
+                f32x16 c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    half8 a;
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const int ih = oh + 2 * h + rr - 2;
+                        u64 t = (unsigned)ih < 6u ? (planes[pl] >> (5 - ih)) & c4::kBottomMask : 0;
+                        unsigned row = (unsigned)((t * 0x41041041040ULL) >> 42) & 0x7F;
+                        unsigned nib = ((row << 2) >> ow) & 0xF;
+#pragma unroll
+                        for (int kw = 0; kw < 4; ++kw) a[rr * 4 + kw] = ((nib >> kw) & 1) ? (_Float16)1.0f : (_Float16)0.0f;
+                    }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bwl[pl], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bwh[pl], c, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (p < IP1) {
+                        const float v = fmaxf(__builtin_fmaf(c[r], inv_sw0, bv_in), 0.f);
+                        _Float16 hi, lo;
+                        split_half(v * sa1, hi, lo);
+                        _Float16 *dst = ldsh_in + (LEAD + j * BS1 + (p / IW1) * W21 + p % IW1) * (PB / 2) + nt * 32 + m;
+                        dst[0] = hi;
+                        dst[128] = lo;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    u32x4 bh[BRING], bl[BRING];
+    float kin2[NB];                                              // 1 / (scale of the middle activations * weight scale)
+    // ---- first 128->128 layer ----
+    {
+        float kin[NB];
+        const float k = sc->inv_sa1 * sc->inv_sw2;
+        static_for<NB>([&](auto J) __attribute__((always_inline)) { kin[decltype(J)::value] = k; });
+        constexpr int OW = IW1 + 1, RC = NB * OW;
+        int cell = sigma(m);
+        cell = cell < RC ? cell : RC - 1;
+        const int lane_base = (LEAD + (cell / OW) * BS1 + cell % OW) * PB + h * 16;
+        f32x16 acc[IH1 + 1];
+#pragma unroll
+        for (int t = 0; t < IH1 + 1; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        const u32x4 *wlh = w2h + h * 128 + nt * 32 + m;
+        const u32x4 *wll = w2l + h * 128 + nt * 32 + m;
+#pragma unroll
+        for (int i = 0; i < BRING - 1; ++i) { bh[i] = wlh[i * 256]; bl[i] = wll[i * 256]; }
+        conv_split_row<IH1, IW1, ARING, BRING, 0>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
+        conv_split_row<IH1, IW1, ARING, BRING, 1>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
+        conv_split_row<IH1, IW1, ARING, BRING, 2>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
+        conv_split_row<IH1, IW1, ARING, BRING, 3>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
+
+        const float bv = bias2[nt * 32 + m];
+        float bmax[NB];
+        static_for<NB>([&](auto J) __attribute__((always_inline)) { bmax[decltype(J)::value] = 0.f; });
+        conv_split_finish<IH1, IW1, NB>(acc, kin, bv, bmax, h);
+        static_for<NB>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            float v = bmax[j];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+            if (lane == 0) s_max[nt * NB + j] = v;
+        });
+        __syncthreads();                                         // every wave is done with the first image
+        float sout[NB], sinv[NB];
+        static_for<NB>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            const float mx = fmaxf(fmaxf(s_max[j], s_max[NB + j]), fmaxf(s_max[2 * NB + j], s_max[3 * NB + j]));
+            sout[j] = pow2_scale(mx, sinv[j]);
+        });
+        // the second image: zeros wherever there is no pixel, the quantised activations where there is one
+        for (int e = tid; e < NPOS2 * 32; e += 256) {
+            const int pos = e >> 5, q = e & 31;
+            const int rel = pos - LEAD, j = rel / BS2, rem = rel - j * BS2, ih = rem / W22, iw = rem - ih * W22;
+            const bool data = rel >= 0 && j < NB && ih < IH2 && iw < IW2;
+            if (!data) lds[pos * SP_RS + q] = zero4;
+        }
+        conv_split_store<IH1, IW1, NB, BS2, W22, LEAD>(acc, sout, reinterpret_cast<unsigned *>(smem_raw), nt * 32 + m, m & 1, h);
+        const float inv_sw4 = sc->inv_sw4;
+        static_for<NB>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            kin2[j] = sinv[j] * inv_sw4;
+        });
+        if constexpr (WRITE_MID) {
+            float my_inv = sinv[0];
+            static_for<NB>([&](auto J) __attribute__((always_inline)) {
+                constexpr int j = decltype(J)::value;
+                my_inv = tid == j ? sinv[j] : my_inv;
+            });
+            if (tid < nb_valid) mid_inv_scale[b0i + tid] = my_inv;
+        }
+        __syncthreads();                                         // the second image is complete (s_max may be reused)
+        if constexpr (WRITE_MID) {
+            u32x4 *dst = mid + (size_t)b0i * IP2 * 32;
+            const int nchunks = nb_valid * IP2 * 32;
+            for (int e = tid; e < nchunks; e += 256) {
+                const int pix = e >> 5, q = e & 31, j = pix / IP2, p = pix - j * IP2;
+                dst[e] = lds[(LEAD + j * BS2 + (p / IW2) * W22 + p % IW2) * SP_RS + q];
+            }
+        }
+    }
+
+    // ---- second 128->128 layer ----
+    constexpr int OW = OW2, RC = NB * OW;
+    int cell = sigma(m);
+    cell = cell < RC ? cell : RC - 1;
+    const int lane_base = (LEAD + (cell / OW) * BS2 + cell % OW) * PB + h * 16;
+    f32x16 acc[OH2];
+#pragma unroll
+    for (int t = 0; t < OH2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const u32x4 *wlh = w4h + h * 128 + nt * 32 + m;
+    const u32x4 *wll = w4l + h * 128 + nt * 32 + m;
+#pragma unroll
+    for (int i = 0; i < BRING - 1; ++i) { bh[i] = wlh[i * 256]; bl[i] = wll[i * 256]; }
+    conv_split_row<IH2, IW2, ARING, BRING, 0>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
+    conv_split_row<IH2, IW2, ARING, BRING, 1>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
+    conv_split_row<IH2, IW2, ARING, BRING, 2>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
+    conv_split_row<IH2, IW2, ARING, BRING, 3>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
+
+    const float bv = bias4[nt * 32 + m];
+    float bmax[NB];
+    static_for<NB>([&](auto J) __attribute__((always_inline)) { bmax[decltype(J)::value] = 0.f; });
+    conv_split_finish<IH2, IW2, NB>(acc, kin2, bv, bmax, h);
+    static_for<NB>([&](auto J) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        float v = bmax[j];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+        if (lane == 0) s_max[nt * NB + j] = v;
+    });
+    __syncthreads();                                             // every wave is done with the second image
+    float sout[NB], sinv[NB];
+    static_for<NB>([&](auto J) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        const float mx = fmaxf(fmaxf(s_max[j], s_max[NB + j]), fmaxf(s_max[2 * NB + j], s_max[3 * NB + j]));
+        sout[j] = pow2_scale(mx, sinv[j]);
+    });
+    conv_split_store<IH2, IW2, NB>(acc, sout, reinterpret_cast<unsigned *>(smem_raw), nt * 32 + m, m & 1, h);
+    __syncthreads();
+    u32x4 *dst = out + (size_t)b0i * OP2 * 32;
+    const int nchunks = nb_valid * OP2 * 32;
+    constexpr int CB = 8;                                        // LDS reads in flight per thread
+    for (int e0 = tid; e0 < nchunks; e0 += 256 * CB) {
+        u32x4 cv[CB];
+        static_for<CB>([&](auto K) __attribute__((always_inline)) {
+            constexpr int k = decltype(K)::value;
+            const int e = min(e0 + 256 * k, nchunks - 1);
+            cv[k] = lds[(e >> 5) * SP_RS + (e & 31)];
+        });
+        static_for<CB>([&](auto K) __attribute__((always_inline)) {
+            constexpr int k = decltype(K)::value;
+            const int e = e0 + 256 * k;
+            if (e < nchunks) dst[e] = cv[k];
+        });
+    }
+    float my_inv = sinv[0];
+    static_for<NB>([&](auto J) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        my_inv = tid == j ? sinv[j] : my_inv;
+    });
+    if (tid < nb_valid) out_inv_scale[b0i + tid] = my_inv;
+}
+
+// ---------------------------------------------------------------------------
 // linear 11520->1024 (network.py:36-39,46-47) with split operands, split in two halves of K.
 // Block tile (32*MTR) rows x 256 columns, 4 waves (one per SIMD); wave w owns columns 64w..64w+63
 // (two 32-column tiles) for all row tiles, so one k-step of 16 is 8 fragment reads from LDS (hi and
@@ -688,14 +930,21 @@ static inline int cdiv_sp(int a, int b) { return (a + b - 1) / b; }
 constexpr int CS_NB = 3;
 constexpr size_t C2S_SPLIT_LDS = conv_split_lds_bytes(7, 8, CS_NB);
 constexpr size_t C4S_SPLIT_LDS = conv_split_lds_bytes(8, 9, CS_NB);
+constexpr size_t CPS_SPLIT_LDS = conv_pair_lds_bytes(CS_NB);
 static_assert(C4S_SPLIT_LDS <= 160 * 1024, "the image of one block must fit the LDS of a CU");
 
 hipError_t prepare_net_kernels_split() {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rows_split_kernel<7, 8, CS_NB, 4, 8, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C2S_SPLIT_LDS);
     if (err != hipSuccess) return err;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rows_split_kernel<8, 9, CS_NB, 4, 8, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C4S_SPLIT_LDS);
+    err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rows_split_kernel<8, 9, CS_NB, 4, 8, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C4S_SPLIT_LDS);
+    if (err != hipSuccess) return err;
+    err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pair_split_kernel<CS_NB, 4, 8, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)CPS_SPLIT_LDS);
+    if (err != hipSuccess) return err;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pair_split_kernel<CS_NB, 4, 8, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)CPS_SPLIT_LDS);
 }
 
 void launch_repack_split(hipStream_t st, const NetWeights &dst, const float *conv0_w, const float *conv0_b,
@@ -729,6 +978,18 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
         conv_rows_split_kernel<7, 8, CS_NB, 4, 8, true><<<cdiv_sp(n_max, CS_NB), 256, C2S_SPLIT_LDS, st>>>(
             nullptr, nullptr, (const u32x4 *)w.conv2_wh, (const u32x4 *)w.conv2_wl, w.conv2_b, w.sp_scales, a2,
             b.act2_inv, count_ptr, n_max, side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b);
+        break;
+    case NET_CONV_PAIR:         // both 128->128 layers (and the 2->128 one) in one launch; act2 stays in LDS
+        conv_pair_split_kernel<CS_NB, 4, 8, false><<<cdiv_sp(n_max, CS_NB), 256, CPS_SPLIT_LDS, st>>>(
+            side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
+            (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b, w.sp_scales,
+            nullptr, nullptr, a3, b.act3_inv, count_ptr, n_max);
+        break;
+    case NET_CONV_PAIR_MID:     // the same, and the middle activations are copied out as the two-launch form leaves them
+        conv_pair_split_kernel<CS_NB, 4, 8, true><<<cdiv_sp(n_max, CS_NB), 256, CPS_SPLIT_LDS, st>>>(
+            side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
+            (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b, w.sp_scales,
+            a2, b.act2_inv, a3, b.act3_inv, count_ptr, n_max);
         break;
     case NET_CONV4:
         conv_rows_split_kernel<8, 9, CS_NB, 4, 8, false><<<cdiv_sp(n_max, CS_NB), 256, C4S_SPLIT_LDS, st>>>(

@@ -87,6 +87,7 @@ struct nnb_engine {
     long long stream_prev[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // cumulative statistics as of the last call's end
     nnb_search_params stream_params = {};
     RoundDev stream_round = {};
+    bool separate_convs = false;           // NNB_FLAG_SEPARATE_CONVS of the call in progress
     bool prof_on = false;
     bool prof_events = false;
     int prof_stride = 1;
@@ -262,6 +263,7 @@ SearchDev to_dev(const nnb_search_params &p) {
 int check_params(nnb_engine *e, const nnb_search_params *p, int n) {
     if (!e) return fail(NNB_ERR_ARG, "engine is null");
     if (!p) return fail(NNB_ERR_ARG, "params is null");
+    e->separate_convs = (p->flags & NNB_FLAG_SEPARATE_CONVS) != 0;
     if (n < 1 || n > e->cfg.max_games)
         return fail(NNB_ERR_ARG, "n = %d out of range [1, max_games = %d]", n, e->cfg.max_games);
     if (p->sims < 1 || p->sims > e->cfg.max_sims)
@@ -335,8 +337,13 @@ void forward_leaves(nnb_engine *e, hipStream_t st, int weight_set, int batch, in
     const size_t o = (size_t)batch * d.max_games;
     const bool fused_in = e->cfg.net_precision != NNB_NET_F32;     // conv0 is part of the conv2 launch there
     if (!fused_in) { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, nb, d.leaf_side + 2 * o, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
-    { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, nb, d.leaf_side + 2 * o, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
-    { ProfScope ps(e, 3, st); net_stage(e, st, NET_CONV4, w, nb, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
+    if (e->cfg.net_precision == NNB_NET_F32S && !e->separate_convs) {
+        // both 128->128 layers in one launch (timed as class 2; class 3 stays empty)
+        ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV_PAIR, w, nb, d.leaf_side + 2 * o, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max);
+    } else {
+        { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, nb, d.leaf_side + 2 * o, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
+        { ProfScope ps(e, 3, st); net_stage(e, st, NET_CONV4, w, nb, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
+    }
     { ProfScope ps(e, 4, st); net_stage(e, st, NET_FC, w, nb, nullptr, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
     if (with_heads) {
         ProfScope ps(e, 5, st);
@@ -771,8 +778,12 @@ int nnb_net_forward(nnb_engine *e, int weight_set, void *stream, int32_t n, cons
     const NetWeights &w = e->weights[weight_set];
     const u64 *side = reinterpret_cast<const u64 *>(side_boards);
     { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, e->buf, side, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
-    { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, e->buf, side, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
-    { ProfScope ps(e, 3, st); net_stage(e, st, NET_CONV4, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+    if (e->cfg.net_precision == NNB_NET_F32S) {         // one launch; the middle activations are copied out for nnb_debug_activations
+        ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV_PAIR_MID, w, e->buf, side, nullptr, nullptr, nullptr, nullptr, nullptr, n);
+    } else {
+        { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, e->buf, side, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+        { ProfScope ps(e, 3, st); net_stage(e, st, NET_CONV4, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+    }
     { ProfScope ps(e, 4, st); net_stage(e, st, NET_FC, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
     { ProfScope ps(e, 5, st); net_stage(e, st, NET_HEADS, w, e->buf, nullptr, legal_masks, log_policy_out, value_out, priors_out, nullptr, n); }
     HIP_TRY(hipGetLastError());
@@ -947,6 +958,7 @@ int nnb_selfplay_stream(nnb_engine *e, void *stream, const nnb_search_params *pa
             return fail(NNB_ERR_ARG, "the search parameters differ from those the stream was started with");
     }
     const nnb_search_params &p = e->stream_params;
+    e->separate_convs = (p.flags & NNB_FLAG_SEPARATE_CONVS) != 0;
     e->dev.n_games = e->stream_slots;
     int make_noise = 0;
     (void)noise_wanted(p, &make_noise);

@@ -97,11 +97,13 @@ class Engine:
                lockstep: bool = False, rng_move_index: int = 0, rng_game_base: int = 0,
                weight_set_colour2: Optional[int] = None, separate_heads: bool = False,
                sync_moves: bool = False, eval_cache: bool = False, side_of_colour=(0, 0),
-               round_limit: int = 0, one_stream: bool = False, two_streams: bool = False) -> SearchParams:
+               round_limit: int = 0, one_stream: bool = False, two_streams: bool = False,
+               separate_convs: bool = False) -> SearchParams:
         ev = EVALUATORS[evaluator] if isinstance(evaluator, str) else int(evaluator)
         md = MODES[mode] if isinstance(mode, str) else int(mode)
         return SearchParams(md, ev, int(sims), int(weight_set), int(bool(lockstep)) | (2 if separate_heads else 0) | (4 if sync_moves else 0)
-                            | (8 if eval_cache else 0) | (16 if one_stream else 0) | (32 if two_streams else 0),
+                            | (8 if eval_cache else 0) | (16 if one_stream else 0) | (32 if two_streams else 0)
+                            | (64 if separate_convs else 0),
                             int(rng_move_index),
                             int(rng_game_base), 0 if weight_set_colour2 is None else int(weight_set_colour2) + 1,
                             float(c_puct), float(dirichlet_alpha), float(dirichlet_eps),

@@ -94,7 +94,11 @@ enum nnb_flags {
      * either way.  Default: two streams from 1024 slots on with NNB_NET_F32S / NNB_NET_F32, one stream with
      * NNB_NET_F16 (where it measured slower).  ONE_STREAM / TWO_STREAMS force the choice. */
     NNB_FLAG_ONE_STREAM = 16,
-    NNB_FLAG_TWO_STREAMS = 32
+    NNB_FLAG_TWO_STREAMS = 32,
+    /* NET evaluator with NNB_NET_F32S: run the two 128->128 convolutions as two launches with the
+     * activations between them in memory, instead of one launch that keeps them in LDS.  Same results
+     * bit for bit; exists so the two forms can be checked against each other. */
+    NNB_FLAG_SEPARATE_CONVS = 64
 };
 
 /* How the network's three big layers multiply.  All accumulate in float32 and keep bias,
