@@ -66,6 +66,7 @@ PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f32s": 2500.0}
 DTYPE_NAME = {"f16": "f16 (f32 accumulate)", "f32": "f32",
               "f32s": "f32 (each operand a hi+lo pair of halves, 3 half-input MFMAs per product, f32 accumulate)"}
 PEAK_HBM_GBS = 8000.0
+KERNEL_NAME = {}
 
 
 def cpu_baseline(sims: int, budget_s: float = 20.0) -> dict:
@@ -322,6 +323,11 @@ def main():
         leaves_per_launch = totals["net_leaves"] / steps_launched          # this rank
         # dominant kernel = largest share of sampled device time
         shares = {k: v["avg_ms"] for k, v in prof.items()}
+        if shares.get("conv4", 0.0) == 0.0 and shares.get("conv2", 0.0) > 0.0 and args.precision == "f32s":
+            # the float32-faithful path runs conv0 + conv2 + conv4 as ONE launch, timed as "conv2"
+            FLOP_PER_LEAF["conv2"] += FLOP_PER_LEAF.pop("conv0") + FLOP_PER_LEAF.pop("conv4")
+            FLOP_PER_LEAF["conv0"] = FLOP_PER_LEAF["conv4"] = 0
+            KERNEL_NAME["conv2"] = "conv0+conv2+conv4 (conv_pair_split_kernel)"
         dom = max(FLOP_PER_LEAF, key=lambda k: shares.get(k, 0.0))
         avg_ms = prof[dom]["avg_ms"]
         achieved = (leaves_per_launch * FLOP_PER_LEAF[dom]) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
@@ -369,7 +375,7 @@ def main():
                       "allgather_ms": gather_ms,
                       "allgather_bytes": world * (NG + PAD) * TRAJECTORY_BYTES if use_dist else 0},
             "kernel_ms": {k: round(v["avg_ms"], 4) for k, v in prof.items()},
-            "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.precision],
+            "roofline": {"kernel": KERNEL_NAME.get(dom, dom), "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.precision],
                          "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": traffic,
                          "traffic_source": traffic_src,
                          "flop_per_leaf": FLOP_PER_LEAF[dom], "leaves_per_launch": leaves_per_launch,
@@ -392,7 +398,7 @@ def main():
             ach = lpl * FLOP_PER_LEAF[dom] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             tr, src = committed_traffic(args.precision, dom, lpl) if standard else (None, None)
             out["roofline_one_chain"] = {
-                "kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+                "kernel": KERNEL_NAME.get(dom, dom), "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
                 "frac": ach / PEAK_TFLOPS[args.precision], "traffic": tr, "traffic_source": src,
                 "leaves_per_launch": lpl, "avg_launch_ms": ms,
                 "issued_frac": ach * mfma_per_product / PEAK_TFLOPS[args.precision],

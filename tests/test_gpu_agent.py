@@ -177,3 +177,40 @@ def test_per_ply_training_samples_follow_the_cpu_game(torch_mod):
         assert z == (0 if result in (0, None) else (1 if (result == 1) == (player == 1) else -1))
         _, player = rp.make_move(board, player, mv)
     assert all((a[0] == b[0]).all() and a[2] == b[2] for a, b in zip(samples[:len(moves)], samples[len(moves):]))
+
+
+def test_weights_file_round_trip_into_the_engine(torch_mod, tmp_path, monkeypatch):
+    """save_agent_model -> load_agent_model (utils.py:33-61: torch.save of the state dict, torch.load with
+    weights_only=True) -> engine: an agent that loaded the file searches exactly as the agent that wrote it,
+    and its first move is the CPU reference search's."""
+    import alphazero_amd.agent as agent_mod
+    from nnbattle.agents.alphazero.utils import initialize_agent, load_agent_model, save_agent_model
+    from nnbattle.game import ConnectFourGame
+    from oracle import ref_port as rp
+    torch = torch_mod
+    torch.manual_seed(123)
+    writer = initialize_agent(action_dim=7, state_dim=2, use_gpu=False, num_simulations=60, c_puct=1.4, load_model=False)
+    path = tmp_path / "alphazero_model_final.pth"
+    save_agent_model(writer, str(path))
+    monkeypatch.setattr(agent_mod, "MODEL_PATH", str(path))
+    torch.manual_seed(999)                                       # the reader's own initial weights differ
+    reader = initialize_agent(action_dim=7, state_dim=2, use_gpu=False, num_simulations=60, c_puct=1.4, load_model=True)
+    assert reader.model_loaded
+    for k, v in writer.model.state_dict().items():
+        assert torch.equal(v, reader.model.state_dict()[k]), k
+    game = ConnectFourGame()
+    game.reset()
+    game.make_move(3); game.make_move(2); game.make_move(3)
+    writer.current_player = reader.current_player = game.current_player
+    aw, pw = writer.select_move(game)
+    ar, pr = reader.select_move(game)
+    assert aw == ar and torch.equal(pw, pr)
+    # against the CPU restatement of the reference search with the same file's weights
+    sd = torch.load(str(path), map_location="cpu", weights_only=True)
+    a_cpu, v_cpu = rp.compat_search(np.array(game.board), game.current_player, 60, 1.4, rp.make_net_evaluator(sd))
+    assert ar == a_cpu
+    assert [int(round(float(p) * 59)) for p in pr] == list(v_cpu)
+    # a missing file is the reference's error (utils.py:50-51)
+    monkeypatch.setattr(agent_mod, "MODEL_PATH", str(tmp_path / "nothing.pth"))
+    with pytest.raises(FileNotFoundError):
+        load_agent_model(reader)

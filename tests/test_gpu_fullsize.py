@@ -24,7 +24,7 @@ def oracle():
     return co, rp
 
 
-def _replay_and_check(co, rec, sims, start_players=None, sample=None):
+def _replay_and_check(co, rec, sims, start_players=None, sample=None, start_boards=None):
     """Replays every record with the rule oracle; returns the set of distinct move sequences."""
     games = set()
     idx = range(len(rec)) if sample is None else sample
@@ -32,8 +32,10 @@ def _replay_and_check(co, rec, sims, start_players=None, sample=None):
         r = rec[i]
         n = int(r["length"])
         b1 = b2 = 0
+        if start_boards is not None:
+            b1, b2 = int(start_boards[i][0]), int(start_boards[i][1])
         player = 1 if start_players is None else int(start_players[i])
-        assert 7 <= n <= 42
+        assert (7 if start_boards is None else 1) <= n <= 42
         for k in range(n):
             ply = r["plies"][k]
             assert (int(ply["colour_boards"][0]), int(ply["colour_boards"][1])) == (b1, b2)
@@ -148,6 +150,52 @@ def test_config5_arena_10000_games_400_sims(gpu, oracle):
         assert all(r["plies"].tobytes() == mine[0]["plies"].tobytes() for r in mine)
         assert mine[0]["plies"]["visits"][:len(moves)].tolist() == visits
         assert (mine["result"] == co.lib().orc_result(b1, b2)).all()
+
+
+def test_config5_arena_10000_games_400_sims_two_networks(gpu, oracle):
+    """The arena at full size with two real networks (seed-0 weights search for colour 1, seed-1 weights for
+    colour 2, run_tournament.py:12-42) in float32-faithful arithmetic: 10 000 games, 400 sims/move, 4096 slots
+    refilled, starters alternate, distinct start positions.  Every 7th record is replayed against the rules;
+    games with the same start position and starter must be identical; and the first plies of one game per
+    starter are searched on the CPU with the reference's rule and the mover's network."""
+    from alphazero_amd.engine import Engine, trajectories_to_numpy
+    from alphazero_amd.game import bits_to_board
+    from alphazero_amd.selfplay import random_openings
+    co, rp = oracle
+    n, sims = 10000, 400
+    sds = [rp.seeded_state_dict(0), rp.seeded_state_dict(1)]
+    starters = (1 + np.arange(n) % 2).astype(np.int8)
+    eng = Engine(max_games=4096, max_sims=sims, n_weight_sets=2)
+    assert eng.precision == "f32s"
+    try:
+        eng.load_state_dict(sds[0], 0)
+        eng.load_state_dict(sds[1], 1)
+        sb, _ = random_openings(eng, n, 4, seed=77)
+        prm = eng.params(sims, 1.4, evaluator="net", weight_set=0, weight_set_colour2=1)
+        traj, stats = eng.selfplay_round(n, prm, start_boards=sb, start_players=starters)
+        rec = trajectories_to_numpy(traj).copy()
+    finally:
+        eng.close()
+    assert stats["games"] == n and stats["sims"] == stats["plies"] * sims
+    assert (rec["result"] != 2).all() and (rec["game_id"] == np.arange(n)).all()
+    games = _replay_and_check(co, rec, sims, start_players=starters, sample=range(0, n, 7), start_boards=sb)
+    assert len(games) > 300
+    seen = {}
+    for i in range(n):
+        key = (int(sb[i][0]), int(sb[i][1]), int(starters[i]))
+        j = seen.setdefault(key, i)
+        assert rec[i]["plies"].tobytes() == rec[j]["plies"].tobytes(), (i, j)
+    assert len(seen) > 500
+    nets = [rp.make_net_evaluator(sd) for sd in sds]
+    evs = [lambda me, opp, f=f: f(bits_to_board(me, opp), 1) for f in nets]
+    for i in (0, 1):                                             # one game per starter, its first two plies
+        r = rec[i]
+        b1, b2, player = int(sb[i][0]), int(sb[i][1]), int(starters[i])
+        for k in range(min(2, int(r["length"]))):
+            a, v, _ = co.compat_search(b1, b2, player, sims, 1.4, evs[player - 1])
+            assert v == r["plies"]["visits"][k].tolist() and a == int(r["plies"]["action"][k]), (i, k)
+            _, b1, b2 = co.drop(b1, b2, player, a)
+            player = 3 - player
 
 
 def test_config2_puct_with_network_is_reproducible_and_slot_independent(gpu, oracle):
