@@ -77,6 +77,10 @@ struct NetBuffers {            // activations, channels-last float32
     float *act2_inv, *act3_inv;           // split-operand path: 1 / scale of each board's activations, [G] each
     float *act2_inv_b1, *act3_inv_b1;
     int max_rows;              // G
+    int shared_chip;           // 1: another forward pass runs beside this one on a second stream (two chains of a
+                               //    self-play round, the two networks of an arena): with 1025..2048 rows the linear
+                               //    layer then runs half as many blocks with twice the rows each, since the companion
+                               //    fills the other CUs and each weight byte fetched serves twice the rows
 };
 enum NetStage { NET_CONV0 = 0, NET_CONV2 = 1, NET_CONV4 = 2, NET_FC = 3, NET_HEADS = 4,
                 // float32-faithful path only: NET_CONV0 + NET_CONV2 + NET_CONV4 as one launch (the activations between the

@@ -735,13 +735,15 @@ template <int MTR, int BR, int ABL = 0>
 __device__ __forceinline__ void fc_split_tile(const u32x4 *__restrict__ a, const float *__restrict__ a_inv_scale,
                                               const u32x4 *__restrict__ wph, const u32x4 *__restrict__ wpl,
                                               const SplitScales *__restrict__ sc, float *__restrict__ part, int count,
-                                              int max_rows, unsigned char *lds) {
+                                              int max_rows, unsigned char *lds, int mbx) {
     const int bid = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, m = lane & 31, h = lane >> 5;
+    // a group of blocks = 8 XCDs x (mbx row blocks x 4 column blocks x 2 K halves); mbx = 4 (256 blocks) or 2 (128)
     const int x = bid & 7, i = bid >> 3;
-    const int grp = i >> 5, ii = i & 31;
-    const int mb = (grp * 8 + x) * 4 + (ii & 3);
-    const int nb = (ii >> 2) & 3, ksp = ii >> 4;
+    const int per = 8 * mbx;
+    const int grp = i / per, ii = i - grp * per;
+    const int mb = (grp * 8 + x) * mbx + ii % mbx;
+    const int nb = (ii / mbx) & 3, ksp = ii / (4 * mbx);
     const int row0 = mb * (32 * MTR);
     if (row0 >= count) return;
     NNB_SP_STAMP(0) NNB_SP_WALL(5)
@@ -900,15 +902,24 @@ __global__ __launch_bounds__(256, 1) void fc_split_kernel(const u32x4 *__restric
                                                           const SplitScales *__restrict__ sc,
                                                           float *__restrict__ part,              // [2][max_rows][1024]
                                                           const int32_t *__restrict__ count_ptr, int n_fixed,
-                                                          int max_rows) {
+                                                          int max_rows, int shared_chip) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * FCS_LBUF];    // three slab buffers
     const int count = batch_count_sp(count_ptr, n_fixed);
-    const int mblocks = gridDim.x >> 3;                      // row blocks the grid provides (8 column/K blocks each)
+    int mblocks = gridDim.x >> 3;                            // row blocks the grid provides (8 column/K blocks each)
+    int mbx = 4;
+    // With a companion forward pass on the chip and 1025..2048 rows, the first 128 blocks take 16 row blocks of 128
+    // rows (where all 256 would take 32 of 64 rows): the companion's kernels fill the other CUs, and every weight
+    // byte a block fetches serves twice the rows.
+    if (shared_chip && gridDim.x == 256 && count > 1024 && count <= 2048) {
+        if (blockIdx.x >= 128) return;
+        mblocks = 16;
+        mbx = 2;
+    }
     const int tiles = (count + 32 * mblocks - 1) / (32 * mblocks);
-    if (tiles <= 1) fc_split_tile<1, BR, ABL>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds);
-    else if (tiles == 2) fc_split_tile<2, BR, ABL>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds);
-    else if (tiles == 3) fc_split_tile<3, BR, ABL>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds);
-    else fc_split_tile<4, BR, ABL>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds);
+    if (tiles <= 1) fc_split_tile<1, BR, ABL>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds, mbx);
+    else if (tiles == 2) fc_split_tile<2, BR, ABL>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds, mbx);
+    else if (tiles == 3) fc_split_tile<3, BR, ABL>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds, mbx);
+    else fc_split_tile<4, BR, ABL>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds, mbx);
 }
 
 // Activations of the split path back to float32 [n][cells][128] (tests and debugging only).
@@ -997,9 +1008,10 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
             b.act3_inv, count_ptr, n_max, nullptr, nullptr, nullptr, nullptr);
         break;
     case NET_FC: {
-        int groups = cdiv_sp(cdiv_sp(n_max, 128), 32);       // 32 row blocks per group of 256 blocks
-        fc_split_kernel<FCS_BR><<<256 * groups, 256, 0, st>>>(a3, b.act3_inv, (const u32x4 *)w.fc_wh, (const u32x4 *)w.fc_wl,
-                                                      w.sp_scales, b.fcpart, count_ptr, n_max, b.max_rows);
+        const int groups = cdiv_sp(cdiv_sp(n_max, 128), 32);       // 32 row blocks per group of 256 blocks
+        fc_split_kernel<FCS_BR><<<256 * groups, 256, 0, st>>>(
+            a3, b.act3_inv, (const u32x4 *)w.fc_wh, (const u32x4 *)w.fc_wl, w.sp_scales, b.fcpart, count_ptr, n_max,
+            b.max_rows, b.shared_chip);
         break;
     }
     case NET_HEADS:     // partial sums have the layout of the half-input path: its heads kernel serves both

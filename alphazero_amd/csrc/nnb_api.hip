@@ -88,6 +88,7 @@ struct nnb_engine {
     nnb_search_params stream_params = {};
     RoundDev stream_round = {};
     bool separate_convs = false;           // NNB_FLAG_SEPARATE_CONVS of the call in progress
+    bool shared_chip = false;              // two forward passes run side by side on two streams
     bool prof_on = false;
     bool prof_events = false;
     int prof_stride = 1;
@@ -313,6 +314,7 @@ void net_stage(nnb_engine *e, hipStream_t st, int stage, const NetWeights &w, co
 // its own, so the two forward passes can run side by side on two streams.
 NetBuffers batch_buffers(const nnb_engine *e, int batch) {
     NetBuffers b = e->buf;
+    b.shared_chip = e->shared_chip ? 1 : 0;
     if (batch == 1) {
         b.fc = b.fc_b1; b.fcpart = b.fcpart_b1;
         b.act1 = b.act1_b1; b.act2 = b.act2_b1; b.act3 = b.act3_b1;
@@ -377,12 +379,14 @@ void lockstep_step(nnb_engine *e, hipStream_t st, const nnb_search_params &p, co
     if (plan.nbatch == 2 && p.evaluator == NNB_EVAL_NET && e->side_stream) {
         // two networks: the second batch's forward pass runs on the engine's side stream, next to the
         // first one's, and joins before the next tree step
+        e->shared_chip = true;
         (void)hipEventRecord(e->fork_event, st);
         (void)hipStreamWaitEvent(e->side_stream, e->fork_event, 0);
         forward_leaves(e, e->side_stream, sd.wset[1], 1, parity, d.n_games, !plan.heads.fused);
         (void)hipEventRecord(e->join_event, e->side_stream);
         forward_leaves(e, st, sd.wset[0], 0, parity, d.n_games, !plan.heads.fused);
         (void)hipStreamWaitEvent(st, e->join_event, 0);
+        e->shared_chip = false;
         return;
     }
     for (int b = 0; b < plan.nbatch; ++b) {
@@ -585,6 +589,7 @@ int run_free_rounds(nnb_engine *e, hipStream_t st, const nnb_search_params &para
     const bool wanted = (p->flags & NNB_FLAG_TWO_STREAMS) ||
                         (slots >= kHalvesMinSlots && e->cfg.net_precision != NNB_NET_F16);
     const bool halves = plan.nbatch == 1 && slots >= 2 * kStepGamesHost && wanted && !(p->flags & NNB_FLAG_ONE_STREAM);
+    e->shared_chip = halves;
     if (halves) {
         const int mid = (slots / 2 + kStepGamesHost - 1) / kStepGamesHost * kStepGamesHost;
         const GameSpan span[2] = {{0, mid, 0}, {mid, slots, 1}};
@@ -616,6 +621,7 @@ int run_free_rounds(nnb_engine *e, hipStream_t st, const nnb_search_params &para
         }
         HIP_TRY(look());
     }
+    e->shared_chip = false;
     *steps_out = steps; *live_out = live; *finished_out = finished; *chains_out = halves ? 2 : 1;
     return NNB_OK;
 }
@@ -660,6 +666,7 @@ int nnb_engine_create(const nnb_config *cfg, void *workspace, size_t workspace_b
     e->cfg = *cfg;
     Carver c(workspace);
     const size_t state_bytes = carve(*cfg, c, e->dev, e->buf, e->weights);
+    e->buf.shared_chip = 0;
     e->weights_loaded.assign(cfg->n_weight_sets, 0);
     HIP_TRY(hipMemsetAsync(workspace, 0, state_bytes, st));
     // log(n + 1) from the host's libm: the same function CPython's math.log calls (mcts.py:29)

@@ -102,7 +102,7 @@ int main(int argc, char **argv) {
         constexpr int BR = decltype(BRc)::value, ABL = decltype(ABLc)::value;
         float t = time_it([&] {
             int groups = cdiv_sp(cdiv_sp(rows, 128), 32);
-            fc_split_kernel<BR, ABL><<<256 * groups, 256, 0, 0>>>(a3, inv, wfh, wfl, sc, part, nullptr, rows, n);
+            fc_split_kernel<BR, ABL><<<256 * groups, 256, 0, 0>>>(a3, inv, wfh, wfl, sc, part, nullptr, rows, n, 0);
         });
         unsigned long long h[8]; CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sp_clk), sizeof h));
         printf("linear 11520->1024, %4d rows, ring %d, ablate %2d: %8.1f us  %7.1f TFLOP/s  block %llu cycles, clock %.0f MHz\n", rows, BR, ABL, t,
