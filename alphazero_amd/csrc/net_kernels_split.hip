@@ -517,10 +517,29 @@ __global__ __launch_bounds__(256, 1) void conv_pair_split_kernel(const u64 *__re
     const int tid = threadIdx.x;
     const int lane = tid & 63, nt = tid >> 6, m = lane & 31, h = lane >> 5;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    NNB_SP_STAMP(0) NNB_SP_WALL(5)
 
     // ---- leaf encode + 2->128 layer into the first image (as conv_rows_split_kernel<.., true>) ----
-    for (int e = tid; e < NPOS1 * SP_RS; e += 256) lds[e] = zero4;
-    __syncthreads();
+    // zeros wherever the 2->128 layer below writes no pixel: the padding positions (enumerated as for the second
+    // image further down), and everything when boards are missing from the block
+    constexpr int PADB1 = 2 * IH1 + (BS1 - IH1 * W21), NPAD1 = LEAD + NB * PADB1 + 2;
+    static_assert(NPAD1 + NB * IP1 == NPOS1, "every position of the image is a pixel or padding");
+    if (nb_valid < NB) {
+        for (int e = tid; e < NPOS1 * SP_RS; e += 256) lds[e] = zero4;
+        __syncthreads();
+    } else {
+        for (int e = tid; e < NPAD1 * 32; e += 256) {
+            const int k = e >> 5, q = e & 31;
+            int pos;
+            if (k < LEAD) pos = k;
+            else if (k >= LEAD + NB * PADB1) pos = LEAD + NB * BS1 + (k - LEAD - NB * PADB1);
+            else {
+                const int kk = k - LEAD, j = kk / PADB1, r = kk - j * PADB1;
+                pos = LEAD + j * BS1 + (r < 2 * IH1 ? (r >> 1) * W21 + IW1 + (r & 1) : IH1 * W21 + (r - 2 * IH1));
+            }
+            lds[pos * SP_RS + q] = zero4;
+        }
+    }
     {
         half8 bwh[2], bwl[2];
 #pragma unroll
@@ -570,6 +589,7 @@ __global__ __launch_bounds__(256, 1) void conv_pair_split_kernel(const u64 *__re
         }
     }
     __syncthreads();
+    NNB_SP_STAMP(1)
 
     u32x4 bh[BRING], bl[BRING];
     float kin2[NB];                                              // 1 / (scale of the middle activations * weight scale)
@@ -595,6 +615,7 @@ __global__ __launch_bounds__(256, 1) void conv_pair_split_kernel(const u64 *__re
         conv_split_row<IH1, IW1, ARING, BRING, 1>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
         conv_split_row<IH1, IW1, ARING, BRING, 2>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
         conv_split_row<IH1, IW1, ARING, BRING, 3>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
+        NNB_SP_STAMP(2)
 
         const float bv = bias2[nt * 32 + m];
         float bmax[NB];
@@ -615,11 +636,20 @@ __global__ __launch_bounds__(256, 1) void conv_pair_split_kernel(const u64 *__re
             sout[j] = pow2_scale(mx, sinv[j]);
         });
         // the second image: zeros wherever there is no pixel, the quantised activations where there is one
-        for (int e = tid; e < NPOS2 * 32; e += 256) {
-            const int pos = e >> 5, q = e & 31;
-            const int rel = pos - LEAD, j = rel / BS2, rem = rel - j * BS2, ih = rem / W22, iw = rem - ih * W22;
-            const bool data = rel >= 0 && j < NB && ih < IH2 && iw < IW2;
-            if (!data) lds[pos * SP_RS + q] = zero4;
+        // (the positions that hold no pixel, enumerated: LEAD in front, per board two behind each image row and the
+        // BS2 - IH2*W22 that pad the board stride, two behind the last board)
+        constexpr int PADB = 2 * IH2 + (BS2 - IH2 * W22), NPAD = LEAD + NB * PADB + 2;
+        static_assert(NPAD + NB * IP2 == NPOS2, "every position of the image is a pixel or padding");
+        for (int e = tid; e < NPAD * 32; e += 256) {
+            const int k = e >> 5, q = e & 31;
+            int pos;
+            if (k < LEAD) pos = k;
+            else if (k >= LEAD + NB * PADB) pos = LEAD + NB * BS2 + (k - LEAD - NB * PADB);
+            else {
+                const int kk = k - LEAD, j = kk / PADB, r = kk - j * PADB;
+                pos = LEAD + j * BS2 + (r < 2 * IH2 ? (r >> 1) * W22 + IW2 + (r & 1) : IH2 * W22 + (r - 2 * IH2));
+            }
+            lds[pos * SP_RS + q] = zero4;
         }
         conv_split_store<IH1, IW1, NB, BS2, W22, LEAD>(acc, sout, reinterpret_cast<unsigned *>(smem_raw), nt * 32 + m, m & 1, h);
         const float inv_sw4 = sc->inv_sw4;
@@ -646,6 +676,7 @@ __global__ __launch_bounds__(256, 1) void conv_pair_split_kernel(const u64 *__re
         }
     }
 
+    NNB_SP_STAMP(4)
     // ---- second 128->128 layer ----
     constexpr int OW = OW2, RC = NB * OW;
     int cell = sigma(m);
@@ -664,6 +695,7 @@ __global__ __launch_bounds__(256, 1) void conv_pair_split_kernel(const u64 *__re
     conv_split_row<IH2, IW2, ARING, BRING, 1>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
     conv_split_row<IH2, IW2, ARING, BRING, 2>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
     conv_split_row<IH2, IW2, ARING, BRING, 3>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
+    NNB_SP_STAMP(7)
 
     const float bv = bias4[nt * 32 + m];
     float bmax[NB];
@@ -707,6 +739,7 @@ __global__ __launch_bounds__(256, 1) void conv_pair_split_kernel(const u64 *__re
         my_inv = tid == j ? sinv[j] : my_inv;
     });
     if (tid < nb_valid) out_inv_scale[b0i + tid] = my_inv;
+    NNB_SP_STAMP(3) NNB_SP_WALL(6)
 }
 
 // ---------------------------------------------------------------------------

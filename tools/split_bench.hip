@@ -69,6 +69,16 @@ int main(int argc, char **argv) {
             act2, inv, w2h, w2l, bias, sc, act3, inv_o, nullptr, n, nullptr, nullptr, nullptr, nullptr);
     });
     report("conv 8x9->9x10", us, (double)n * 2 * 128 * 90 * 2048);
+    us = time_it([&] {
+        conv_pair_split_kernel<CS_NB, 4, 8, false><<<cdiv_sp(n, CS_NB), 256, CPS_SPLIT_LDS, 0>>>(
+            side, w0h, w0l, bias, w2h, w2l, bias, w2h, w2l, bias, sc, nullptr, nullptr, act3, inv_o, nullptr, n);
+    });
+    {
+        unsigned long long h[8]; CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sp_clk), sizeof h));
+        printf("both convs in one launch          %8.1f us  %7.1f TFLOP/s   block: 2->128 %llu  main1 %llu  epilogue1 %llu  main2 %llu  epilogue2 %llu  total %llu cycles  clock %.0f MHz\n",
+               us, (double)n * 2 * 128 * (72 + 90) * 2048 / (us * 1e-6) / 1e12, h[1] - h[0], h[2] - h[1], h[4] - h[2], h[7] - h[4], h[3] - h[7], h[3] - h[0],
+               (double)(h[3] - h[0]) / (double)(h[6] - h[5]) * 100.0);
+    }
     {   // two half batches on two streams (conv 7x8 + conv 8x9 each) against the same work on one stream
         hipStream_t s1, s2; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
         const int nh = n / 2;
