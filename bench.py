@@ -25,9 +25,11 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                  the MI355X dense peak of the matrix instruction it issues (half inputs: 2.5 PFLOP/s;
                  exact f32: 157.3 TFLOP/s); its duration is sampled with HIP events on the stream the
                  kernel is launched on, inside the timed region (16 launches of every 64 lock-step rounds).
-                 With two chains on two streams (concurrent_chains = 2) a launch shares the chip with the other
-                 chain's kernel, so region_frac gives the network's algorithmic FLOPs of the whole timed region
-                 over its duration, and roofline_one_chain the same kernel with the chip to itself;
+                 The timed region runs two chains on two streams, where a launch shares the chip with the other
+                 chain's kernel: those durations are reported as roofline_timed_region (with region_frac, the
+                 network's algorithmic FLOPs of the whole timed region over its wall time), and `roofline` itself
+                 comes from one more step, right after the timed region, with all games in ONE chain (N=1 only;
+                 with --one-stream or at N>1 `roofline` is measured inside the timed region);
   cpu_baseline : the CPU restatement of the reference path (oracle/ref_port.py: numpy board,
                  one game at a time, batch-1 torch-CPU forward) timed on this box's host cores
                  on a bounded sample, at 200 and at 100 simulations per move (rank 0, N=1 only);
@@ -392,19 +394,28 @@ def main():
                               "avg_launch_ms": tree_ms},
         }
         if prof_one is not None:
+            out["roofline_timed_region"] = out["roofline"]
+            out["roofline_timed_region"]["note"] = (
+                "launch durations by HIP events on each chain's own stream inside the timed region: a launch there shares "
+                "the chip with the other chain's kernels, so its duration overstates the time its work takes; region_frac "
+                "is the network's algorithmic FLOPs of the whole timed region over the region's wall time")
             p1, st1 = prof_one
             lpl = st1["net_leaves"] / max(st1["steps"], 1)
             ms = p1[dom]["avg_ms"]
             ach = lpl * FLOP_PER_LEAF[dom] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             tr, src = committed_traffic(args.precision, dom, lpl) if standard else (None, None)
-            out["roofline_one_chain"] = {
+            out["roofline"] = {
                 "kernel": KERNEL_NAME.get(dom, dom), "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
                 "frac": ach / PEAK_TFLOPS[args.precision], "traffic": tr, "traffic_source": src,
                 "leaves_per_launch": lpl, "avg_launch_ms": ms,
                 "issued_frac": ach * mfma_per_product / PEAK_TFLOPS[args.precision],
+                "flop_per_leaf": FLOP_PER_LEAF[dom], "mfma_per_product": mfma_per_product,
                 "kernel_ms": {k: round(v["avg_ms"], 4) for k, v in p1.items()},
-                "note": "one more step outside the timed region with all games in one chain (bench.py --one-stream "
-                        "times the whole run that way): every kernel has the chip to itself"}
+                "measured": "HIP events on the launch stream over one more step of the same stream of games, run right "
+                            "after the timed region with all games in ONE chain, so that every kernel has the chip to "
+                            "itself (the timed region runs two chains on two streams: see roofline_timed_region; "
+                            "`bench.py --one-stream` times the whole run in one chain, and profiles/*_one_chain_* is "
+                            "its rocprofv3 summary)"}
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.sims)
