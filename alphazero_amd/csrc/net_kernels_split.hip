@@ -123,6 +123,12 @@ __global__ void repack_conv0_split_kernel(const float *__restrict__ w, const flo
 // leaf encode (AlphaZeroAgent.preprocess, agent_code.py:76-89) and the 2->128 convolution
 // (network.py:29-30) from the side boards, with the layer's static output scale.
 // ---------------------------------------------------------------------------
+// The hi or lo weights of one 128->128 layer (16 taps x 8 k-steps x 4 KB) as a buffer resource: a fragment load is
+// then one instruction with a per-lane 32-bit offset and a scalar offset, and a read past the end returns zeros.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t conv_weight_rsrc(const u32x4 *w) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(w), 0, 128 * 128 * 16 * 2, 0x00027000);
+}
+
 // All four taps of kernel row KH.  The code of a block should stay resident in the instruction cache (64 KB
 // shared by two CUs; straight-line code that misses it runs at ~20 cycles per instruction), so there is ONE
 // body per kernel row: the tap loop is a real loop, the fragment ring is refilled across taps under a uniform
@@ -130,7 +136,7 @@ __global__ void repack_conv0_split_kernel(const float *__restrict__ w, const flo
 template <int IH, int IW, int ARING, int BRING, int KH>
 __device__ __forceinline__ void conv_split_row(f32x16 (&acc)[IH + 1], u32x4 (&bh)[BRING], u32x4 (&bl)[BRING],
                                                const unsigned char *smem, int lane_base,
-                                               const u32x4 *__restrict__ wlh, const u32x4 *__restrict__ wll) {
+                                               const __amdgpu_buffer_rsrc_t &rwh, const __amdgpu_buffer_rsrc_t &rwl, int woff) {
     constexpr int W2 = IW + 2, PB = SP_PB;
     constexpr int T0 = rows_t0(KH), NT = rows_t1(IH, KH) - T0, STEPS = 8 * NT;
     static_assert(STEPS % ARING == 0, "ring depth must divide the fragment pairs per tap");
@@ -151,11 +157,10 @@ __device__ __forceinline__ void conv_split_row(f32x16 (&acc)[IH + 1], u32x4 (&bh
         const int step0 = (KH * 4 + kw) * 8;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            {                                                    // weights BRING-1 k-steps ahead
-                int nxt = step0 + ks + BRING - 1;
-                nxt = nxt < 128 ? nxt : 127;
-                bh[(ks + BRING - 1) & (BRING - 1)] = wlh[nxt * 256];
-                bl[(ks + BRING - 1) & (BRING - 1)] = wll[nxt * 256];
+            {                                                    // weights BRING-1 k-steps ahead: buffer loads with a scalar
+                const int nxt = step0 + ks + BRING - 1;            // offset per k-step (no 64-bit address arithmetic per lane);
+                bh[(ks + BRING - 1) & (BRING - 1)] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, nxt * 4096, 0);   // past the last
+                bl[(ks + BRING - 1) & (BRING - 1)] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, nxt * 4096, 0);   // k-step: zeros, unused
             }
             const half8 wh = as_half8(bh[ks & (BRING - 1)]), wl = as_half8(bl[ks & (BRING - 1)]);
 #pragma unroll
@@ -406,15 +411,18 @@ __global__ __launch_bounds__(256, 1) void conv_rows_split_kernel(const u32x4 *__
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const u32x4 *wlh = wph + h * 128 + nt * 32 + m;
-    const u32x4 *wll = wpl + h * 128 + nt * 32 + m;
+    const __amdgpu_buffer_rsrc_t rwh = conv_weight_rsrc(wph), rwl = conv_weight_rsrc(wpl);
+    const int woff = (h * 128 + nt * 32 + m) * 16;
     u32x4 bh[BRING], bl[BRING];
 #pragma unroll
-    for (int i = 0; i < BRING - 1; ++i) { bh[i] = wlh[i * 256]; bl[i] = wll[i * 256]; }
-    conv_split_row<IH, IW, ARING, BRING, 0>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
-    conv_split_row<IH, IW, ARING, BRING, 1>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
-    conv_split_row<IH, IW, ARING, BRING, 2>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
-    conv_split_row<IH, IW, ARING, BRING, 3>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
+    for (int i = 0; i < BRING - 1; ++i) {
+        bh[i] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, i * 4096, 0);
+        bl[i] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, i * 4096, 0);
+    }
+    conv_split_row<IH, IW, ARING, BRING, 0>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
+    conv_split_row<IH, IW, ARING, BRING, 1>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
+    conv_split_row<IH, IW, ARING, BRING, 2>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
+    conv_split_row<IH, IW, ARING, BRING, 3>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
 
     NNB_SP_STAMP(2)
     // epilogue: bias + ReLU in float32, each board's maximum over the whole block, then hi / lo with
@@ -592,6 +600,7 @@ __global__ __launch_bounds__(256, 1) void conv_pair_split_kernel(const u64 *__re
     NNB_SP_STAMP(1)
 
     u32x4 bh[BRING], bl[BRING];
+    const int woff = (h * 128 + nt * 32 + m) * 16;              // this lane's weight fragment inside a k-step's 4 KB
     float kin2[NB];                                              // 1 / (scale of the middle activations * weight scale)
     // ---- first 128->128 layer ----
     {
@@ -607,14 +616,16 @@ __global__ __launch_bounds__(256, 1) void conv_pair_split_kernel(const u64 *__re
         for (int t = 0; t < IH1 + 1; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        const u32x4 *wlh = w2h + h * 128 + nt * 32 + m;
-        const u32x4 *wll = w2l + h * 128 + nt * 32 + m;
+        const __amdgpu_buffer_rsrc_t rwh = conv_weight_rsrc(w2h), rwl = conv_weight_rsrc(w2l);
 #pragma unroll
-        for (int i = 0; i < BRING - 1; ++i) { bh[i] = wlh[i * 256]; bl[i] = wll[i * 256]; }
-        conv_split_row<IH1, IW1, ARING, BRING, 0>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
-        conv_split_row<IH1, IW1, ARING, BRING, 1>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
-        conv_split_row<IH1, IW1, ARING, BRING, 2>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
-        conv_split_row<IH1, IW1, ARING, BRING, 3>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
+        for (int i = 0; i < BRING - 1; ++i) {
+            bh[i] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, i * 4096, 0);
+            bl[i] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, i * 4096, 0);
+        }
+        conv_split_row<IH1, IW1, ARING, BRING, 0>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
+        conv_split_row<IH1, IW1, ARING, BRING, 1>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
+        conv_split_row<IH1, IW1, ARING, BRING, 2>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
+        conv_split_row<IH1, IW1, ARING, BRING, 3>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
         NNB_SP_STAMP(2)
 
         const float bv = bias2[nt * 32 + m];
@@ -687,14 +698,16 @@ __global__ __launch_bounds__(256, 1) void conv_pair_split_kernel(const u64 *__re
     for (int t = 0; t < OH2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const u32x4 *wlh = w4h + h * 128 + nt * 32 + m;
-    const u32x4 *wll = w4l + h * 128 + nt * 32 + m;
+    const __amdgpu_buffer_rsrc_t rwh = conv_weight_rsrc(w4h), rwl = conv_weight_rsrc(w4l);
 #pragma unroll
-    for (int i = 0; i < BRING - 1; ++i) { bh[i] = wlh[i * 256]; bl[i] = wll[i * 256]; }
-    conv_split_row<IH2, IW2, ARING, BRING, 0>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
-    conv_split_row<IH2, IW2, ARING, BRING, 1>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
-    conv_split_row<IH2, IW2, ARING, BRING, 2>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
-    conv_split_row<IH2, IW2, ARING, BRING, 3>(acc, bh, bl, smem_raw, lane_base, wlh, wll);
+    for (int i = 0; i < BRING - 1; ++i) {
+        bh[i] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, i * 4096, 0);
+        bl[i] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, i * 4096, 0);
+    }
+    conv_split_row<IH2, IW2, ARING, BRING, 0>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
+    conv_split_row<IH2, IW2, ARING, BRING, 1>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
+    conv_split_row<IH2, IW2, ARING, BRING, 2>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
+    conv_split_row<IH2, IW2, ARING, BRING, 3>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
     NNB_SP_STAMP(7)
 
     const float bv = bias4[nt * 32 + m];
