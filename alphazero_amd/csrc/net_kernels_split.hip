@@ -968,6 +968,74 @@ __global__ __launch_bounds__(256, 1) void fc_split_kernel(const u32x4 *__restric
     else fc_split_tile<4, BR, ABL>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds, mbx);
 }
 
+// Small batches (at most 128 rows: single searches, small tournaments, the last games of a round) are
+// latency-bound, and fc_split_kernel would give a handful of rows to 8 blocks.  Here a block is ONE wave that
+// owns 32 rows x 32 columns x one half of K, so 32 rows spread over 64 CUs.  Fragments go memory -> registers
+// (activations: 16 bytes per lane straight from the [row][cell][hi | lo] layout; weights as in fc_split_kernel)
+// through a ring DEPTH k-steps deep.  Every output sums the same products in the same order as in
+// fc_split_kernel (k-steps ascending inside a K half; hi*lo, lo*hi, hi*hi per k-step), so the results are
+// the same bit for bit whatever the batch size.
+template <int DEPTH>
+__global__ __launch_bounds__(64) void fc_split_small_kernel(const u32x4 *__restrict__ a, const float *__restrict__ a_inv_scale,
+                                                            const u32x4 *__restrict__ wph, const u32x4 *__restrict__ wpl,
+                                                            const SplitScales *__restrict__ sc, float *__restrict__ part,
+                                                            const int32_t *__restrict__ count_ptr, int n_fixed, int max_rows) {
+    const int count = batch_count_sp(count_ptr, n_fixed);
+    const int bid = blockIdx.x, rt = bid >> 6, ct = (bid >> 1) & 31, ksp = bid & 1;
+    const int row0 = rt * 32;
+    if (row0 >= count) return;
+    const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
+    constexpr int KHALF = FCS_K / FCS_SPLIT, NKS = KHALF / 16;           // 360 k-steps of 16
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a), 0, max_rows * FCS_ROW_BYTES, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(wph), 0, FCS_K * FCS_N * 2, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(wpl), 0, FCS_K * FCS_N * 2, 0x00027000);
+    // activation fragment of k-step K (global index): 64 k per 256-byte half cell (128 B of hi at +0 / +128, lo 256 B
+    // further): byte (K >> 3) * 512 + ((K >> 2) & 1) * 128 + (K & 3) * 32 + h * 16 of the row
+    const int arow = min(row0 + m, max_rows - 1);
+    const int aoff = arow * FCS_ROW_BYTES + h * 16;
+    auto a_bytes = [&](int K) __attribute__((always_inline)) { return (K >> 3) * 512 + ((K >> 2) & 1) * 128 + (K & 3) * 32; };
+    // weight fragment of k-step K: ((K * 2 + h) * 1024 + n) * 16 bytes, n = 32 ct + m
+    const int woff = (h * FCS_N + ct * 32 + m) * 16;
+    constexpr int WKS = 2 * FCS_N * 16;
+    const int k0 = ksp * NKS;
+    u32x4 xh[DEPTH], xl[DEPTH], wh[DEPTH], wl[DEPTH];
+    static_for<DEPTH - 1>([&](auto Jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(Jc)::value;
+        xh[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff, a_bytes(k0 + j), 0);
+        xl[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff + 256, a_bytes(k0 + j), 0);
+        wh[j] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, (k0 + j) * WKS, 0);
+        wl[j] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, (k0 + j) * WKS, 0);
+    });
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    static_assert(NKS % DEPTH == 0, "the k loop is unrolled by the ring depth");
+    for (int kb = 0; kb < NKS; kb += DEPTH) {
+        static_for<DEPTH>([&](auto Jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(Jc)::value;
+            constexpr int fill = (j + DEPTH - 1) % DEPTH;
+            int kn = kb + j + DEPTH - 1;
+            kn = k0 + (kn < NKS ? kn : NKS - 1);                         // past the end: read again, never used
+            xh[fill] = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff, a_bytes(kn), 0);
+            xl[fill] = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff + 256, a_bytes(kn), 0);
+            wh[fill] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, kn * WKS, 0);
+            wl[fill] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, kn * WKS, 0);
+            const half8 ah = as_half8(xh[j]), al = as_half8(xl[j]), bh = as_half8(wh[j]), bl = as_half8(wl[j]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    const float inv_sw = sc->inv_swf;
+    float *obase = part + (size_t)ksp * max_rows * FCS_N + ct * 32 + m;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < count) obase[(size_t)row * FCS_N] = acc[r] * (a_inv_scale[row] * inv_sw);
+    }
+}
+
 // Activations of the split path back to float32 [n][cells][128] (tests and debugging only).
 __global__ void split_to_f32_kernel(const _Float16 *__restrict__ act, const float *__restrict__ inv_scale,
                                     int cells, int n, float *__restrict__ out) {
@@ -984,6 +1052,7 @@ __global__ void split_to_f32_kernel(const _Float16 *__restrict__ act, const floa
 // ---------------------------------------------------------------------------
 static inline int cdiv_sp(int a, int b) { return (a + b - 1) / b; }
 
+constexpr int kSplitSmallBatch = 128;        // at most this many rows: the one-wave linear-layer blocks
 constexpr int CS_NB = 3;
 constexpr size_t C2S_SPLIT_LDS = conv_split_lds_bytes(7, 8, CS_NB);
 constexpr size_t C4S_SPLIT_LDS = conv_split_lds_bytes(8, 9, CS_NB);
@@ -1054,6 +1123,12 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
             b.act3_inv, count_ptr, n_max, nullptr, nullptr, nullptr, nullptr);
         break;
     case NET_FC: {
+        if (n_max <= kSplitSmallBatch) {                         // one wave per 32 rows x 32 columns x K half
+            fc_split_small_kernel<12><<<64 * cdiv_sp(n_max, 32), 64, 0, st>>>(
+                a3, b.act3_inv, (const u32x4 *)w.fc_wh, (const u32x4 *)w.fc_wl, w.sp_scales, b.fcpart, count_ptr, n_max,
+                b.max_rows);
+            break;
+        }
         const int groups = cdiv_sp(cdiv_sp(n_max, 128), 32);       // 32 row blocks per group of 256 blocks
         fc_split_kernel<FCS_BR><<<256 * groups, 256, 0, st>>>(
             a3, b.act3_inv, (const u32x4 *)w.fc_wh, (const u32x4 *)w.fc_wl, w.sp_scales, b.fcpart, count_ptr, n_max,
