@@ -133,19 +133,27 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t conv_weight_rsrc(const u32x4 *
 // shared by two CUs; straight-line code that misses it runs at ~20 cycles per instruction), so there is ONE
 // body per kernel row: the tap loop is a real loop, the fragment ring is refilled across taps under a uniform
 // predicate and primed again at the start of each kernel row.
-template <int IH, int IW, int ARING, int BRING, int KH>
-__device__ __forceinline__ void conv_split_row(f32x16 (&acc)[IH + 1], u32x4 (&bh)[BRING], u32x4 (&bl)[BRING],
+//
+// TROWS = output rows per MFMA tile.  1: a tile is one output row of all the block's boards, and the tiles whose
+// kernel row KH reads only padding are skipped.  3 (one board per block, small batches): a tile is three
+// consecutive output rows of the board, every tile takes every kernel row, and the image carries two rows of zero
+// positions above and below the board.  Either way an output sums the same non-zero products in the same order.
+template <int IH, int IW, int ARING, int BRING, int KH, int TROWS = 1, int NACC = IH + 1>
+__device__ __forceinline__ void conv_split_row(f32x16 (&acc)[NACC], u32x4 (&bh)[BRING], u32x4 (&bl)[BRING],
                                                const unsigned char *smem, int lane_base,
                                                const __amdgpu_buffer_rsrc_t &rwh, const __amdgpu_buffer_rsrc_t &rwl, int woff) {
     constexpr int W2 = IW + 2, PB = SP_PB;
-    constexpr int T0 = rows_t0(KH), NT = rows_t1(IH, KH) - T0, STEPS = 8 * NT;
+    constexpr int T0 = TROWS == 1 ? rows_t0(KH) : 0;
+    constexpr int NT = TROWS == 1 ? rows_t1(IH, KH) - T0 : (IH + TROWS) / TROWS, STEPS = 8 * NT;
+    constexpr int TS = TROWS * W2 * PB;                          // bytes between consecutive tiles in the image
+    static_assert(T0 + NT <= NACC, "one accumulator per tile");
     static_assert(STEPS % ARING == 0, "ring depth must divide the fragment pairs per tap");
     u32x4 ahi[ARING], alo[ARING];
     {
         const unsigned char *p0 = smem + lane_base + ((KH - 2) * W2 - 2) * PB;
 #pragma unroll
         for (int f = 0; f < ARING; ++f) {
-            const unsigned char *p = p0 + (T0 + f % NT) * (W2 * PB) + (f / NT) * 32;
+            const unsigned char *p = p0 + (T0 + f % NT) * TS + (f / NT) * 32;
             ahi[f] = *reinterpret_cast<const u32x4 *>(p);
             alo[f] = *reinterpret_cast<const u32x4 *>(p + SP_LO);
         }
@@ -171,12 +179,12 @@ __device__ __forceinline__ void conv_split_row(f32x16 (&acc)[IH + 1], u32x4 (&bh
                 acc[T0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, acc[T0 + i], 0, 0, 0);
                 acc[T0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, acc[T0 + i], 0, 0, 0);
                 if (g < STEPS) {
-                    const unsigned char *p = pv + (T0 + g % NT) * (W2 * PB) + (g / NT) * 32;
+                    const unsigned char *p = pv + (T0 + g % NT) * TS + (g / NT) * 32;
                     ahi[g % ARING] = *reinterpret_cast<const u32x4 *>(p);
                     alo[g % ARING] = *reinterpret_cast<const u32x4 *>(p + SP_LO);
                 } else if (more) {                               // first fragments of the next tap
                     const int gg = g - STEPS;
-                    const unsigned char *p = pv + PB + (T0 + gg % NT) * (W2 * PB) + (gg / NT) * 32;
+                    const unsigned char *p = pv + PB + (T0 + gg % NT) * TS + (gg / NT) * 32;
                     ahi[g % ARING] = *reinterpret_cast<const u32x4 *>(p);
                     alo[g % ARING] = *reinterpret_cast<const u32x4 *>(p + SP_LO);
                 }
@@ -756,6 +764,248 @@ __global__ __launch_bounds__(256, 1) void conv_pair_split_kernel(const u64 *__re
 }
 
 // ---------------------------------------------------------------------------
+// conv_pair_split_kernel for small batches (single searches, small tournaments, the last games of a round): ONE
+// board per block, so a handful of boards spreads over as many CUs, and an MFMA tile is three consecutive output
+// rows of the board (27 or 30 of 32 cells) instead of one row of three boards - 3 tiles per layer where the
+// large-batch form issues 8 and 9.  Same halves, same per-board scales, same order of the non-zero products per
+// output: results equal conv_pair_split_kernel's bit for bit.
+// ---------------------------------------------------------------------------
+// Image of one board: two lead positions, 12 image rows of iw + 2 positions (two rows of zeros above the board, the
+// board's rows, zeros below: the three tiles cover output rows 0..8, whose last kernel row reads image row 9 + 2),
+// two tail positions.
+constexpr int conv_small_positions(int ih, int iw) { return 2 + (ih + 4 > 12 ? ih + 4 : 12) * (iw + 2) + 2; }
+constexpr size_t conv_pair_small_lds_bytes() {
+    int a = conv_small_positions(7, 8), b = conv_small_positions(8, 9), c = 9 * 10;
+    int m = a > b ? a : b;
+    return (size_t)(m > c ? m : c) * SP_PB + 64;
+}
+
+// this lane's maximum of ReLU(acc * k + bias) over its cells; a tile's cell c is row 3t + c / OW, column c % OW
+template <int OH, int OW, int NT>
+__device__ __forceinline__ float conv_small_max(const f32x16 (&acc)[NT], float k, float bv, int h) {
+    float mx = 0.f;
+    static_for<16>([&](auto Rr) __attribute__((always_inline)) {
+        constexpr int r = decltype(Rr)::value;
+        constexpr int c0 = sigma((r & 3) + 8 * (r >> 2)), c1 = sigma((r & 3) + 8 * (r >> 2) + 4);
+        static_for<NT>([&](auto T) __attribute__((always_inline)) {
+            constexpr int t = decltype(T)::value;
+            constexpr bool l0 = c0 < 3 * OW && 3 * t + c0 / OW < OH, l1 = c1 < 3 * OW && 3 * t + c1 / OW < OH;
+            const float v = fmaxf(__builtin_fmaf(acc[t][r], k, bv), 0.f);
+            mx = fmaxf(mx, (h ? l1 : l0) ? v : 0.f);
+        });
+    });
+    return mx;
+}
+
+// ReLU(acc * k + bias) quantised with the board's scale, hi / lo into LDS position LEADO + row * RSO + column
+// (the lane-pair packing of conv_split_store)
+template <int OH, int OW, int NT, int RSO, int LEADO>
+__device__ __forceinline__ void conv_small_store(const f32x16 (&acc)[NT], float k, float bv, float sc_out, unsigned *ldsw,
+                                                 int ch, int odd, int h) {
+    const int col = (ch >> 1) + (odd ? SP_LO / 4 : 0);
+    const unsigned psel = odd ? 0x03020706u : 0x05040100u;
+    static_for<16>([&](auto Rr) __attribute__((always_inline)) {
+        constexpr int r = decltype(Rr)::value;
+        constexpr int c0 = sigma((r & 3) + 8 * (r >> 2)), c1 = sigma((r & 3) + 8 * (r >> 2) + 4);
+        static_for<NT>([&](auto T) __attribute__((always_inline)) {
+            constexpr int t = decltype(T)::value;
+            constexpr bool l0 = c0 < 3 * OW && 3 * t + c0 / OW < OH, l1 = c1 < 3 * OW && 3 * t + c1 / OW < OH;
+            constexpr int P0 = l0 ? LEADO + (3 * t + c0 / OW) * RSO + c0 % OW : 0;
+            constexpr int P1 = l1 ? LEADO + (3 * t + c1 / OW) * RSO + c1 % OW : 0;
+            if (h ? l1 : l0) {
+                typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+                half2v pr;
+                const float x = fmaxf(__builtin_fmaf(acc[t][r], k, bv), 0.f) * sc_out;
+                pr[0] = (_Float16)x;
+                pr[1] = (_Float16)(x - (float)pr[0]);
+                const unsigned own = __builtin_bit_cast(unsigned, pr);
+                const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);   // lane ^ 1
+                ldsw[(h ? P1 : P0) * (SP_PB / 4) + col] = __builtin_amdgcn_perm(other, own, psel);
+            }
+        });
+    });
+}
+
+template <int BRING, int ARING, bool WRITE_MID>
+__global__ __launch_bounds__(256, 2) void conv_pair_split_small_kernel(const u64 *__restrict__ side,
+                                                                       const u32x4 *__restrict__ w0h,
+                                                                       const u32x4 *__restrict__ w0l,
+                                                                       const float *__restrict__ b0,
+                                                                       const u32x4 *__restrict__ w2h,
+                                                                       const u32x4 *__restrict__ w2l,
+                                                                       const float *__restrict__ bias2,
+                                                                       const u32x4 *__restrict__ w4h,
+                                                                       const u32x4 *__restrict__ w4l,
+                                                                       const float *__restrict__ bias4,
+                                                                       const SplitScales *__restrict__ sc,
+                                                                       u32x4 *__restrict__ mid, float *__restrict__ mid_inv_scale,
+                                                                       u32x4 *__restrict__ out, float *__restrict__ out_inv_scale,
+                                                                       const int32_t *__restrict__ count_ptr, int n_fixed) {
+    constexpr int PB = SP_PB;
+    constexpr int IH1 = 7, IW1 = 8, IP1 = IH1 * IW1, W21 = IW1 + 2, NPOS1 = conv_small_positions(IH1, IW1), LEAD1 = 2 + 2 * W21;
+    constexpr int IH2 = 8, IW2 = 9, IP2 = IH2 * IW2, W22 = IW2 + 2, NPOS2 = conv_small_positions(IH2, IW2), LEAD2 = 2 + 2 * W22;
+    constexpr int OH1 = IH1 + 1, OW1 = IW1 + 1, OH2 = IH2 + 1, OW2 = IW2 + 1, OP2 = OH2 * OW2;
+    constexpr int NT = 3;
+    static_assert((OH1 + 2) / 3 == NT && (OH2 + 2) / 3 == NT && 3 * OW2 <= 32, "three tiles of three rows per layer");
+    constexpr int REGION = (NPOS2 > NPOS1 ? (NPOS2 > OP2 ? NPOS2 : OP2) : (NPOS1 > OP2 ? NPOS1 : OP2)) * PB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4 *lds = reinterpret_cast<u32x4 *>(smem_raw);
+    float *s_max = reinterpret_cast<float *>(smem_raw + REGION);     // [4 waves]
+
+    const int count = batch_count_sp(count_ptr, n_fixed);
+    const int board = blockIdx.x;
+    if (board >= count) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, nt = tid >> 6, m = lane & 31, h = lane >> 5;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    // ---- leaf encode + 2->128 layer into the first image ----
+    for (int e = tid; e < NPOS1 * SP_RS; e += 256) lds[e] = zero4;
+    __syncthreads();
+    {
+        half8 bwh[2], bwl[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            bwh[pl] = as_half8(w0h[(nt * 32 + m) * 4 + 2 * pl + h]);
+            bwl[pl] = as_half8(w0l[(nt * 32 + m) * 4 + 2 * pl + h]);
+        }
+        const float bv_in = b0[nt * 32 + m];
+        const float inv_sw0 = sc->inv_sw0, sa1 = sc->sa1;
+        _Float16 *ldsh_in = reinterpret_cast<_Float16 *>(smem_raw);
+        const u64 planes[2] = {side[2 * board], side[2 * board + 1]};
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int pos = mt * 32 + m, oh = pos >> 3, ow = pos & 7;
+            f32x16 c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                half8 a;
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int ih = oh + 2 * h + rr - 2;
+                    u64 t = (unsigned)ih < 6u ? (planes[pl] >> (5 - ih)) & c4::kBottomMask : 0;
+                    unsigned row = (unsigned)((t * 0x41041041040ULL) >> 42) & 0x7F;
+                    unsigned nib = ((row << 2) >> ow) & 0xF;
+#pragma unroll
+                    for (int kw = 0; kw < 4; ++kw) a[rr * 4 + kw] = ((nib >> kw) & 1) ? (_Float16)1.0f : (_Float16)0.0f;
+                }
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bwl[pl], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bwh[pl], c, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (p < IP1) {
+                    const float v = fmaxf(__builtin_fmaf(c[r], inv_sw0, bv_in), 0.f);
+                    _Float16 hi, lo;
+                    split_half(v * sa1, hi, lo);
+                    _Float16 *dst = ldsh_in + (LEAD1 + (p / IW1) * W21 + p % IW1) * (PB / 2) + nt * 32 + m;
+                    dst[0] = hi;
+                    dst[128] = lo;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    u32x4 bh[BRING], bl[BRING];
+    const int woff = (h * 128 + nt * 32 + m) * 16;
+    const int ch = nt * 32 + m;
+    float k2;                                                    // 1 / (scale of the middle activations * weight scale)
+    // ---- first 128->128 layer ----
+    {
+        const float k1 = sc->inv_sa1 * sc->inv_sw2;
+        int cell = sigma(m);
+        cell = cell < 3 * OW1 ? cell : 3 * OW1 - 1;
+        const int lane_base = (LEAD1 + (cell / OW1) * W21 + cell % OW1) * PB + h * 16;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        const __amdgpu_buffer_rsrc_t rwh = conv_weight_rsrc(w2h), rwl = conv_weight_rsrc(w2l);
+#pragma unroll
+        for (int i = 0; i < BRING - 1; ++i) {
+            bh[i] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, i * 4096, 0);
+            bl[i] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, i * 4096, 0);
+        }
+        conv_split_row<IH1, IW1, ARING, BRING, 0, 3, NT>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
+        conv_split_row<IH1, IW1, ARING, BRING, 1, 3, NT>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
+        conv_split_row<IH1, IW1, ARING, BRING, 2, 3, NT>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
+        conv_split_row<IH1, IW1, ARING, BRING, 3, 3, NT>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
+
+        const float bv = bias2[ch];
+        float v = conv_small_max<OH1, OW1, NT>(acc, k1, bv, h);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+        if (lane == 0) s_max[nt] = v;
+        __syncthreads();                                         // every wave is done with the first image
+        float sinv;
+        const float sout = pow2_scale(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])), sinv);
+        // the second image: zeros wherever there is no pixel (two rows above, two positions behind every image row,
+        // two rows and the tail below), the quantised activations where there is one
+        constexpr int TOP = LEAD2, BOT = NPOS2 - (LEAD2 + IH2 * W22), NPAD = TOP + 2 * IH2 + BOT;
+        static_assert(NPAD + IP2 == NPOS2, "every position of the image is a pixel or padding");
+        for (int e = tid; e < NPAD * 32; e += 256) {
+            const int kk = e >> 5, q = e & 31;
+            const int pos = kk < TOP ? kk
+                          : kk < TOP + 2 * IH2 ? LEAD2 + ((kk - TOP) >> 1) * W22 + IW2 + ((kk - TOP) & 1)
+                                               : LEAD2 + IH2 * W22 + (kk - TOP - 2 * IH2);
+            lds[pos * SP_RS + q] = zero4;
+        }
+        conv_small_store<OH1, OW1, NT, W22, LEAD2>(acc, k1, bv, sout, reinterpret_cast<unsigned *>(smem_raw), ch, m & 1, h);
+        k2 = sinv * sc->inv_sw4;
+        if constexpr (WRITE_MID) {
+            if (tid == 0) mid_inv_scale[board] = sinv;
+        }
+        __syncthreads();                                         // the second image is complete (s_max may be reused)
+        if constexpr (WRITE_MID) {
+            u32x4 *dst = mid + (size_t)board * IP2 * 32;
+            for (int e = tid; e < IP2 * 32; e += 256) {
+                const int p = e >> 5, q = e & 31;
+                dst[e] = lds[(LEAD2 + (p / IW2) * W22 + p % IW2) * SP_RS + q];
+            }
+        }
+    }
+
+    // ---- second 128->128 layer ----
+    int cell = sigma(m);
+    cell = cell < 3 * OW2 ? cell : 3 * OW2 - 1;
+    const int lane_base = (LEAD2 + (cell / OW2) * W22 + cell % OW2) * PB + h * 16;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const __amdgpu_buffer_rsrc_t rwh = conv_weight_rsrc(w4h), rwl = conv_weight_rsrc(w4l);
+#pragma unroll
+    for (int i = 0; i < BRING - 1; ++i) {
+        bh[i] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, i * 4096, 0);
+        bl[i] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, i * 4096, 0);
+    }
+    conv_split_row<IH2, IW2, ARING, BRING, 0, 3, NT>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
+    conv_split_row<IH2, IW2, ARING, BRING, 1, 3, NT>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
+    conv_split_row<IH2, IW2, ARING, BRING, 2, 3, NT>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
+    conv_split_row<IH2, IW2, ARING, BRING, 3, 3, NT>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
+
+    const float bv = bias4[ch];
+    float v = conv_small_max<OH2, OW2, NT>(acc, k2, bv, h);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    if (lane == 0) s_max[nt] = v;
+    __syncthreads();                                             // every wave is done with the second image
+    float sinv;
+    const float sout = pow2_scale(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])), sinv);
+    conv_small_store<OH2, OW2, NT, OW2, 0>(acc, k2, bv, sout, reinterpret_cast<unsigned *>(smem_raw), ch, m & 1, h);
+    __syncthreads();
+    u32x4 *dst = out + (size_t)board * OP2 * 32;
+    for (int e = tid; e < OP2 * 32; e += 256) dst[e] = lds[(e >> 5) * SP_RS + (e & 31)];
+    if (tid == 0) out_inv_scale[board] = sinv;
+}
+
+// ---------------------------------------------------------------------------
 // linear 11520->1024 (network.py:36-39,46-47) with split operands, split in two halves of K.
 // Block tile (32*MTR) rows x 256 columns, 4 waves (one per SIMD); wave w owns columns 64w..64w+63
 // (two 32-column tiles) for all row tiles, so one k-step of 16 is 8 fragment reads from LDS (hi and
@@ -1069,8 +1319,14 @@ hipError_t prepare_net_kernels_split() {
     err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pair_split_kernel<CS_NB, 4, 8, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)CPS_SPLIT_LDS);
     if (err != hipSuccess) return err;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pair_split_kernel<CS_NB, 4, 8, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)CPS_SPLIT_LDS);
+    err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pair_split_kernel<CS_NB, 4, 8, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)CPS_SPLIT_LDS);
+    if (err != hipSuccess) return err;
+    err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pair_split_small_kernel<4, 8, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_pair_small_lds_bytes());
+    if (err != hipSuccess) return err;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pair_split_small_kernel<4, 8, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_pair_small_lds_bytes());
 }
 
 void launch_repack_split(hipStream_t st, const NetWeights &dst, const float *conv0_w, const float *conv0_b,
@@ -1106,12 +1362,26 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
             b.act2_inv, count_ptr, n_max, side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b);
         break;
     case NET_CONV_PAIR:         // both 128->128 layers (and the 2->128 one) in one launch; act2 stays in LDS
+        if (n_max <= kSplitSmallBatch) {                         // one board per block
+            conv_pair_split_small_kernel<4, 8, false><<<n_max, 256, conv_pair_small_lds_bytes(), st>>>(
+                side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
+                (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b,
+                w.sp_scales, nullptr, nullptr, a3, b.act3_inv, count_ptr, n_max);
+            break;
+        }
         conv_pair_split_kernel<CS_NB, 4, 8, false><<<cdiv_sp(n_max, CS_NB), 256, CPS_SPLIT_LDS, st>>>(
             side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
             (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b, w.sp_scales,
             nullptr, nullptr, a3, b.act3_inv, count_ptr, n_max);
         break;
     case NET_CONV_PAIR_MID:     // the same, and the middle activations are copied out as the two-launch form leaves them
+        if (n_max <= kSplitSmallBatch) {
+            conv_pair_split_small_kernel<4, 8, true><<<n_max, 256, conv_pair_small_lds_bytes(), st>>>(
+                side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
+                (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b,
+                w.sp_scales, a2, b.act2_inv, a3, b.act3_inv, count_ptr, n_max);
+            break;
+        }
         conv_pair_split_kernel<CS_NB, 4, 8, true><<<cdiv_sp(n_max, CS_NB), 256, CPS_SPLIT_LDS, st>>>(
             side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
             (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b, w.sp_scales,

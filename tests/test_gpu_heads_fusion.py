@@ -83,3 +83,29 @@ def test_one_launch_and_two_launch_convolutions_agree(rp, mode):
         assert np.asarray(one[2], dtype=np.float64).tobytes() == value.cpu().numpy().astype(np.float64).tobytes()
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("precision", ["f32s", "f16"])
+def test_small_batch_and_large_batch_kernels_agree_bit_for_bit(rp, precision):
+    """Batches of at most 128 positions run latency-oriented forms of the network kernels (one board per
+    convolution block, one wave per linear-layer block); larger ones the throughput forms.  A position's
+    outputs and hidden activations must not depend on which form evaluated it."""
+    import torch
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.selfplay import random_openings
+    eng = Engine(max_games=400, max_sims=8, precision=precision)
+    try:
+        eng.load_state_dict(rp.seeded_state_dict(0), 0)
+        sb, sp = random_openings(eng, 400, 6, seed=9)
+        side = np.where(sp[:, None] == 1, sb, sb[:, ::-1]).astype(np.uint64)
+        legal = eng.game_ops(sb)[1]
+        big = eng.net_forward(side, legal)                          # 400 rows: the large-batch kernels
+        acts_big = [eng.activations(layer, 100).clone() for layer in (2, 3, 4)]
+        for n in (1, 2, 3, 31, 100, 128):
+            small = eng.net_forward(side[:n], legal[:n])            # at most 128 rows: the small-batch kernels
+            for a, b in zip(big, small):
+                assert torch.equal(a[:n], b), n
+            for layer, ref in zip((2, 3, 4), acts_big):
+                assert torch.equal(eng.activations(layer, min(n, 100)), ref[:min(n, 100)]), (n, layer)
+    finally:
+        eng.close()
