@@ -89,6 +89,9 @@ struct nnb_engine {
     RoundDev stream_round = {};
     bool separate_convs = false;           // NNB_FLAG_SEPARATE_CONVS of the call in progress
     bool shared_chip = false;              // two forward passes run side by side on two streams
+    int row_bound = 0;                     // > 0: no leaf batch of the rounds being launched holds more rows than this
+                                           //      (the occupied slots at the host's last look; they only go down until
+                                           //      the next look), so the forward pass may pick its small-batch kernels
     bool prof_on = false;
     bool prof_events = false;
     int prof_stride = 1;
@@ -265,6 +268,8 @@ int check_params(nnb_engine *e, const nnb_search_params *p, int n) {
     if (!e) return fail(NNB_ERR_ARG, "engine is null");
     if (!p) return fail(NNB_ERR_ARG, "params is null");
     e->separate_convs = (p->flags & NNB_FLAG_SEPARATE_CONVS) != 0;
+    e->row_bound = 0;
+    e->shared_chip = false;
     if (n < 1 || n > e->cfg.max_games)
         return fail(NNB_ERR_ARG, "n = %d out of range [1, max_games = %d]", n, e->cfg.max_games);
     if (p->sims < 1 || p->sims > e->cfg.max_sims)
@@ -332,6 +337,7 @@ HeadsDev heads_input(const nnb_engine *e, int weight_set, int batch) {
 // Forward pass over one of the engine's compacted leaf batches (count on the device).  With
 // `with_heads` false it stops after the linear layer; the tree step computes the heads.
 void forward_leaves(nnb_engine *e, hipStream_t st, int weight_set, int batch, int parity, int n_max, bool with_heads) {
+    if (e->row_bound > 0 && e->row_bound < n_max) n_max = e->row_bound;
     const int32_t *count_ptr = e->dev.leaf_count + 2 * parity + batch;
     const NetWeights &w = e->weights[weight_set];
     const EngineDev &d = e->dev;
@@ -566,6 +572,8 @@ int run_free_rounds(nnb_engine *e, hipStream_t st, const nnb_search_params &para
     HIP_TRY(hipStreamSynchronize(st));
     int live = e->host_counters[0];
     long long finished = (unsigned)e->host_counters[1];
+    // occupied slots never increase between two looks (a slot is refilled at the moment it empties, or not at all)
+    e->row_bound = live > 0 ? live : 1;
     auto go_on = [&]() { return live > 0 && steps < max_steps && (finish_target < 0 || finished < finish_target); };
     auto look = [&]() -> hipError_t {
         hipError_t err = hipGetLastError();
@@ -577,6 +585,7 @@ int run_free_rounds(nnb_engine *e, hipStream_t st, const nnb_search_params &para
         prof_drain(e);
         live = e->host_counters[0];
         finished = (unsigned)e->host_counters[1];
+        e->row_bound = live > 0 ? live : 1;
         return hipSuccess;
     };
     // One network and enough slots: the slots are split in two halves, each with a leaf batch, activation
@@ -622,6 +631,7 @@ int run_free_rounds(nnb_engine *e, hipStream_t st, const nnb_search_params &para
         HIP_TRY(look());
     }
     e->shared_chip = false;
+    e->row_bound = 0;
     *steps_out = steps; *live_out = live; *finished_out = finished; *chains_out = halves ? 2 : 1;
     return NNB_OK;
 }
