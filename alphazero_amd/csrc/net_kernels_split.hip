@@ -1218,7 +1218,7 @@ __global__ __launch_bounds__(256, 1) void fc_split_kernel(const u32x4 *__restric
     else fc_split_tile<4, BR, ABL>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds, mbx);
 }
 
-// Small batches (at most 128 rows: single searches, small tournaments, the last games of a round) are
+// Small batches (at most kSplitSmallFc rows: single searches, small tournaments, the last games of a round) are
 // latency-bound, and fc_split_kernel would give a handful of rows to 8 blocks.  Here a block is ONE wave that
 // owns 32 rows x 32 columns x one half of K, so 32 rows spread over 64 CUs.  Fragments go memory -> registers
 // (activations: 16 bytes per lane straight from the [row][cell][hi | lo] layout; weights as in fc_split_kernel)
@@ -1302,7 +1302,10 @@ __global__ void split_to_f32_kernel(const _Float16 *__restrict__ act, const floa
 // ---------------------------------------------------------------------------
 static inline int cdiv_sp(int a, int b) { return (a + b - 1) / b; }
 
-constexpr int kSplitSmallBatch = 128;        // at most this many rows: the one-wave linear-layer blocks
+// Up to this many rows the latency-oriented forms run (one board per convolution block, one wave per linear-layer
+// block).  Measured whole forward passes, small / large forms: 128 rows 86 / 176 us, 256 rows 129 / 181 us,
+// 384 rows 198 / 193 us, 512 rows 246 / 198 us (tools/net_latency.py).
+constexpr int kSplitSmallConv = 256, kSplitSmallFc = 256;
 constexpr int CS_NB = 3;
 constexpr size_t C2S_SPLIT_LDS = conv_split_lds_bytes(7, 8, CS_NB);
 constexpr size_t C4S_SPLIT_LDS = conv_split_lds_bytes(8, 9, CS_NB);
@@ -1362,7 +1365,7 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
             b.act2_inv, count_ptr, n_max, side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b);
         break;
     case NET_CONV_PAIR:         // both 128->128 layers (and the 2->128 one) in one launch; act2 stays in LDS
-        if (n_max <= kSplitSmallBatch) {                         // one board per block
+        if (n_max <= kSplitSmallConv) {                          // one board per block
             conv_pair_split_small_kernel<4, 8, false><<<n_max, 256, conv_pair_small_lds_bytes(), st>>>(
                 side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
                 (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b,
@@ -1375,7 +1378,7 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
             nullptr, nullptr, a3, b.act3_inv, count_ptr, n_max);
         break;
     case NET_CONV_PAIR_MID:     // the same, and the middle activations are copied out as the two-launch form leaves them
-        if (n_max <= kSplitSmallBatch) {
+        if (n_max <= kSplitSmallConv) {
             conv_pair_split_small_kernel<4, 8, true><<<n_max, 256, conv_pair_small_lds_bytes(), st>>>(
                 side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
                 (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b,
@@ -1393,7 +1396,7 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
             b.act3_inv, count_ptr, n_max, nullptr, nullptr, nullptr, nullptr);
         break;
     case NET_FC: {
-        if (n_max <= kSplitSmallBatch) {                         // one wave per 32 rows x 32 columns x K half
+        if (n_max <= kSplitSmallFc) {                            // one wave per 32 rows x 32 columns x K half
             fc_split_small_kernel<12><<<64 * cdiv_sp(n_max, 32), 64, 0, st>>>(
                 a3, b.act3_inv, (const u32x4 *)w.fc_wh, (const u32x4 *)w.fc_wl, w.sp_scales, b.fcpart, count_ptr, n_max,
                 b.max_rows);

@@ -87,7 +87,7 @@ def test_one_launch_and_two_launch_convolutions_agree(rp, mode):
 
 @pytest.mark.parametrize("precision", ["f32s", "f16"])
 def test_small_batch_and_large_batch_kernels_agree_bit_for_bit(rp, precision):
-    """Batches of at most 128 positions run latency-oriented forms of the network kernels (one board per
+    """Batches of at most 128 (half inputs) or 256 (float32-faithful) positions run latency-oriented forms of the network kernels (one board per
     convolution block, one wave per linear-layer block); larger ones the throughput forms.  A position's
     outputs and hidden activations must not depend on which form evaluated it."""
     import torch
@@ -101,8 +101,8 @@ def test_small_batch_and_large_batch_kernels_agree_bit_for_bit(rp, precision):
         legal = eng.game_ops(sb)[1]
         big = eng.net_forward(side, legal)                          # 400 rows: the large-batch kernels
         acts_big = [eng.activations(layer, 100).clone() for layer in (2, 3, 4)]
-        for n in (1, 2, 3, 31, 100, 128):
-            small = eng.net_forward(side[:n], legal[:n])            # at most 128 rows: the small-batch kernels
+        for n in (1, 2, 3, 31, 100, 128, 250):
+            small = eng.net_forward(side[:n], legal[:n])            # the small-batch kernels (f16: up to 128 rows)
             for a, b in zip(big, small):
                 assert torch.equal(a[:n], b), n
             for layer, ref in zip((2, 3, 4), acts_big):
