@@ -815,9 +815,11 @@ __device__ void readout_game(const EngineDev &e, const SearchDev &p, int g, int3
         note_finished(e, round, e.traj_index[g]);
         // the slot takes the next unplayed game of the round, if any
         bool seated = false;
+        int tries = 0;
         while (!seated) {
             int j = e.n_games + atomicAdd(&e.counters[kRefills], 1);
-            if (j >= round.total_games) break;
+            // (an endless stream whose start positions are all finished must not keep this lane here for ever)
+            if (j >= round.total_games || (round.total_games >= kEndlessGames && ++tries > kSeatTries)) break;
             seated = seat_game(e, round, g, j);
         }
         if (!seated) { e.active[g] = 0; atomicSub(&e.counters[kLive], 1); }
@@ -857,9 +859,10 @@ __global__ void selfplay_init_kernel(EngineDev e, RoundDev round) {
     for (int k = 0; k < 8; ++k) e.game_stats[8 * g + k] = 0;
     e.ply[g] = 0;
     bool seated = seat_game(e, round, g, g);
+    int tries = 0;
     while (!seated) {
         int j = e.n_games + atomicAdd(&e.counters[kRefills], 1);
-        if (j >= round.total_games) break;
+        if (j >= round.total_games || (round.total_games >= kEndlessGames && ++tries > kSeatTries)) break;
         seated = seat_game(e, round, g, j);
     }
     e.active[g] = seated ? 1 : 0;

@@ -102,3 +102,17 @@ def test_stream_argument_checks(gpu):
             eng.selfplay_stream(1, eng.params(8, 2.0, evaluator="hash_q8", lockstep=True))
     finally:
         eng.close()
+
+
+def test_stream_of_finished_start_positions_ends(gpu):
+    """Start positions that are all finished: every game is recorded as it is seated, no slot ever holds a game,
+    and the call must come back (with what it recorded) instead of seating for ever."""
+    from alphazero_amd.engine import Engine
+    eng = Engine(max_games=16, max_sims=8)
+    try:
+        p = eng.params(8, 1.4, evaluator="hash_q8", lockstep=True)
+        won = np.array([[0b1111, 0b1110000000]], dtype=np.uint64)          # colour 1 has four in the first column
+        with pytest.raises(Exception, match="stopped"):
+            eng.selfplay_stream(10 ** 6, p, restart=True, start_boards=won, start_players=np.array([2], dtype=np.int8))
+    finally:
+        eng.close()
