@@ -33,10 +33,11 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   cpu_baseline : the CPU restatement of the reference path (oracle/ref_port.py: numpy board,
                  one game at a time, batch-1 torch-CPU forward) timed on this box's host cores
                  on a bounded sample, at 200 and at 100 simulations per move (rank 0, N=1 only);
-  single_round_identical_games, f16_inputs, with_eval_cache (N=1 only, each timed on its own, none part
-                 of `value`): the 4096 games from the empty board the reference itself would play (one game,
-                 4096 times); the headline workload with half-precision network inputs; and with the
-                 per-game evaluation cache.
+  single_round_identical_games, single_round_distinct_games, with_eval_cache, az_mode, f16_inputs (N=1 only,
+                 each timed on its own, none part of `value`): the 4096 games from the empty board the reference
+                 itself would play (one game, 4096 times) as one plain round; 16384 of the timed region's games as
+                 one plain round; the stream with the per-game evaluation cache; a stream under the PUCT rule with
+                 Dirichlet root noise; and the headline stream with half-precision network inputs.
 """
 from __future__ import annotations
 
@@ -286,6 +287,20 @@ def main():
             lambda: one_step(engine, cparams, "cache", gather=False),
             "one more step of the same stream with the per-game evaluation cache: a leaf whose position its game has "
             "already evaluated is not sent to the network again; same trajectories; the reference evaluates every leaf")
+        azp = engine.params(args.sims, C_PUCT, evaluator="net", mode="az", dirichlet_alpha=0.3, dirichlet_eps=0.25, seed=0)
+        az_state = {"first": True}
+
+        def az_step():
+            first, az_state["first"] = az_state["first"], False
+            _, st = engine.selfplay_stream(NG, azp if first else None, restart=first)
+            return st
+        for _ in range(2):
+            az_step()
+        extra["az_mode"] = timed(
+            az_step,
+            "one step of a stream of games from the empty board under the PUCT rule with the network's priors and "
+            "engine-drawn Dirichlet(0.3) root noise mixed in at 0.25 (counter-based RNG, seed 0): a search the reference "
+            "does not have (its expand drops the priors), held to this repository's own CPU restatement only")
         if args.precision != "f16":
             e16 = Engine(max_games=G, max_sims=args.sims, device=device, precision="f16")
             e16.load_state_dict(seeded_state_dict(0))
