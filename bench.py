@@ -274,8 +274,7 @@ def main():
         extra["single_round_identical_games"] = timed(
             lambda: one_plain_round(engine, params, G, (None, None)),
             f"one plain round (nnb_selfplay_round) of {G} games from the empty board, no refill: the reference's search "
-            "is deterministic, so this is one game played on every slot, all slots in step (best-case batch fill, "
-            "the round-1 workload)")
+            "is deterministic, so this is one game played on every slot, all slots in step (best-case batch fill)")
         extra["single_round_distinct_games"] = timed(
             lambda: one_plain_round(engine, params, 4 * G, (starts[0], starts[1])),
             f"one plain round of {4 * G} games from the timed region's start positions on {G} slots, played until the "
