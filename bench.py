@@ -14,7 +14,7 @@ inside the region, whichever game they belong to.  (A plain round of games playe
 ended is reported as single_round_*.)
 The reference's search is deterministic, so its games from the empty board are all the same game;
 the timed games therefore start from OPENING_PLIES uniformly random legal moves (16384 drawn start
-positions per rank, at most 7^4 of them distinct).  Weak scaling: per-GPU work is fixed.
+positions per rank; 1119 of them are distinct).  Weak scaling: per-GPU work is fixed.
 
     python bench.py --gpus 1 --steps 1 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
