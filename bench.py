@@ -160,6 +160,11 @@ def main():
                          "(python -m torch.distributed.run --nproc-per-node N ...)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible")
+    # Rehearsal of the multi-rank code on a box with ONE GPU (never used by a real run): every rank on cuda:0 and
+    # the collectives over gloo, since RCCL refuses two ranks on one device.
+    rehearsal = os.environ.get("NNB_BENCH_REHEARSAL_ONE_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # Under a launcher (RANK set) the collective path runs even with one rank, so the single-GPU
@@ -173,7 +178,10 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=device)
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=device)
             dist.barrier()
             torch.cuda.synchronize(device)
         finally:
