@@ -336,7 +336,12 @@ int nnb_selfplay_round(nnb_engine *engine, void *stream, const nnb_search_params
  * reused ring_len games later, so the caller copies finished records out between calls (a game that lasts
  * while ring_len - max_games later games are seated would be overwritten; no legal game does at 4 x).
  * stats_out counts the work of this call only.  Any other call that searches or runs the network on this
- * engine ends the stream (the next call needs restart != 0).  Synchronous. */
+ * engine ends the stream (the next call needs restart != 0).  nnb_load_weights between two calls does not:
+ * the games in flight carry on and every later leaf is judged by the new weights, as when the training loop
+ * updates the model between two self_play calls (entries a game has filed in the evaluation cache under the
+ * old weights stay until that game ends, so leave NNB_FLAG_EVAL_CACHE off when weights change).  The per-slot
+ * statistics behind stats_out are 32-bit: restart the stream before a slot has run 2^31 simulations (about
+ * 9 * 10^5 games per slot at 200 simulations per move).  Synchronous. */
 int nnb_selfplay_stream(nnb_engine *engine, void *stream, const nnb_search_params *params, int32_t restart,
                         int32_t first_game_id, int32_t min_finished, const uint64_t *start_colour_boards,
                         const int8_t *start_players, int32_t n_starts, nnb_trajectory *record_ring,

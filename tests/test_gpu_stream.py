@@ -116,3 +116,38 @@ def test_stream_of_finished_start_positions_ends(gpu):
             eng.selfplay_stream(10 ** 6, p, restart=True, start_boards=won, start_players=np.array([2], dtype=np.int8))
     finally:
         eng.close()
+
+
+def test_weights_reloaded_between_calls_of_a_stream(gpu):
+    """The training loop's pattern: self-play, new weights, more self-play, without emptying the slots.  Games seated
+    after the reload must equal the games a plain round plays with the new weights; games finished before it those of
+    the old weights; the ones in flight across the reload are only required to be legal games."""
+    from alphazero_amd.engine import Engine, trajectories_to_numpy
+    from alphazero_amd.network import seeded_state_dict
+    from alphazero_amd.selfplay import random_openings
+    slots, sims, n_starts = 32, 16, 256
+    eng = Engine(max_games=slots, max_sims=sims)
+    try:
+        sd_a, sd_b = seeded_state_dict(0), seeded_state_dict(1)
+        eng.load_state_dict(sd_a)
+        params = eng.params(sims, 1.4, evaluator="net", mode="compat")
+        sb, sp = random_openings(eng, n_starts, 6, seed=4)
+        r1, st1 = eng.selfplay_stream(40, params, restart=True, start_boards=sb, start_players=sp)
+        seated_at_reload = st1["finished_total"] + slots            # ids below this were seated under the old weights
+        eng.load_state_dict(sd_b)
+        r2, st2 = eng.selfplay_stream(120)
+        old, new = trajectories_to_numpy(r1).copy(), trajectories_to_numpy(r2).copy()
+        assert (old["result"] != 2).all() and (new["result"] != 2).all()
+        assert (old["game_id"] < seated_at_reload).all()
+        late = new[new["game_id"] >= seated_at_reload]
+        assert len(late) > 20
+        n = int(max(old["game_id"].max(), new["game_id"].max())) + 1
+        sel = np.arange(n) % n_starts
+        ref_b = trajectories_to_numpy(eng.selfplay_round(n, params, start_boards=sb[sel], start_players=sp[sel])[0]).copy()
+        assert late.tobytes() == ref_b[late["game_id"]].tobytes()
+        eng.load_state_dict(sd_a)
+        ref_a = trajectories_to_numpy(eng.selfplay_round(n, params, start_boards=sb[sel], start_players=sp[sel])[0]).copy()
+        assert old.tobytes() == ref_a[old["game_id"]].tobytes()
+        assert (ref_a[late["game_id"]]["plies"].tobytes() != late["plies"].tobytes())      # the weights matter
+    finally:
+        eng.close()
