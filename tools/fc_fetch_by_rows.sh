@@ -1,0 +1,24 @@
+#!/bin/bash
+# Fabric-side read bytes of the float32-faithful linear layer as a function of the row count.  The kernel uses row
+# tiles of 32*t rows, t = ceil(rows / 1024), and deals its row blocks to the 8 XCDs in groups of four, so the row count
+# decides how many XCDs take part; each of them fetches the whole weight matrix once.  One FETCH_SIZE pass per size.
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+out=gpurun_out/fc_fetch
+rm -rf "$out"; mkdir -p "$out"
+for n in 512 1024 2048 4096; do
+  timeout -s KILL 120 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$out/n$n" -o run -- python3 tools/net_latency.py $n > "$out/n$n.log" 2>&1 || exit 1
+  python3 - "$out/n$n" $n <<'PY'
+import csv, glob, sys
+d, n = sys.argv[1], int(sys.argv[2])
+vals = [float(r["Counter_Value"]) for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+        for r in csv.DictReader(open(f)) if r["Counter_Name"] == "FETCH_SIZE" and "fc_split_kernel" in r["Kernel_Name"]]
+act, w = n * 46080 / 1e6, 47.2
+t = (n + 1023) // 1024
+row_blocks = (n + 32 * t - 1) // (32 * t)
+xcds = min(8, (row_blocks + 3) // 4)
+print(f"rows {n}: {len(vals)} launches, FETCH_SIZE x 2 = {2 * sum(vals) / len(vals) * 1024 / 1e6:.1f} MB per launch; "
+      f"activations {act:.1f} MB + weights {w} MB x {xcds} XCDs = {act + w * xcds:.1f} MB")
+PY
+  rm -rf "$out/n$n"
+done

@@ -6,7 +6,8 @@ from alphazero_amd.engine import Engine
 from alphazero_amd.network import seeded_state_dict
 eng = Engine(max_games=4096, max_sims=8)
 eng.load_state_dict(seeded_state_dict(0))
-for n in (64, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048):
+sizes = [int(a) for a in sys.argv[1:]] or [64, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048]
+for n in sizes:
     side = np.zeros((n, 2), dtype=np.uint64)
     side_t = torch.from_numpy(side.view("int64")).to(eng.device)
     eng.net_forward(side_t)
