@@ -974,6 +974,10 @@ int nnb_selfplay_stream(nnb_engine *e, void *stream, const nnb_search_params *pa
         if (params && memcmp(params, &e->stream_params, sizeof *params) != 0)
             return fail(NNB_ERR_ARG, "the search parameters differ from those the stream was started with");
     }
+    if (min_finished > e->stream_round.ring_len - 2 * e->stream_slots)
+        return fail(NNB_ERR_ARG, "min_finished = %d: a call's records must fit the ring beside the games in flight "
+                    "(at most ring_len - 2 x max_games = %d per call)", min_finished,
+                    e->stream_round.ring_len - 2 * e->stream_slots);
     const nnb_search_params &p = e->stream_params;
     e->separate_convs = (p.flags & NNB_FLAG_SEPARATE_CONVS) != 0;
     e->dev.n_games = e->stream_slots;

@@ -332,7 +332,8 @@ int nnb_selfplay_round(nnb_engine *engine, void *stream, const nnb_search_params
  * the call returns once at least min_finished more games have finished; games in flight stay seated.
  * finished_ring (device, ring_len ints, may be NULL): entry k % ring_len = index into record_ring of the
  * k-th game to finish since the restart; with stats_out->finished_total = F after the call and
- * stats_out->games = f, this call's records are entries F-f .. F-1.  ring_len >= 4 * max_games; a record is
+ * stats_out->games = f, this call's records are entries F-f .. F-1.  ring_len >= 4 * max_games and
+ * min_finished <= ring_len - 2 * max_games (a call's records must fit the ring beside the games in flight); a record is
  * reused ring_len games later, so the caller copies finished records out between calls (a game that lasts
  * while ring_len - max_games later games are seated would be overwritten; no legal game does at 4 x).
  * stats_out counts the work of this call only.  Any other call that searches or runs the network on this

@@ -98,6 +98,8 @@ def test_stream_argument_checks(gpu):
         assert st["games"] == 0 and r.shape[0] == 0
         r, st = eng.selfplay_stream(5)
         assert st["games"] >= 5
+        with pytest.raises(Exception, match="fit the ring"):
+            eng.selfplay_stream(8 * 16 - 2 * 16 + 1)
         with pytest.raises(Exception, match="differ"):
             eng.selfplay_stream(1, eng.params(8, 2.0, evaluator="hash_q8", lockstep=True))
     finally:
@@ -112,8 +114,10 @@ def test_stream_of_finished_start_positions_ends(gpu):
     try:
         p = eng.params(8, 1.4, evaluator="hash_q8", lockstep=True)
         won = np.array([[0b1111, 0b1110000000]], dtype=np.uint64)          # colour 1 has four in the first column
-        with pytest.raises(Exception, match="stopped"):
-            eng.selfplay_stream(10 ** 6, p, restart=True, start_boards=won, start_players=np.array([2], dtype=np.int8))
+        r, st = eng.selfplay_stream(96, p, restart=True, start_boards=won, start_players=np.array([2], dtype=np.int8))
+        assert st["games"] >= 96 and st["sims"] == 0                       # recorded, never played; every slot gave up
+        with pytest.raises(Exception, match="stopped"):                     # nothing is seated any more
+            eng.selfplay_stream(1)
     finally:
         eng.close()
 
