@@ -438,3 +438,31 @@ def test_net_search_sided_positions(seed0_engine, oracle, sided_golden):
     else:
         assert same == len(cases)
         assert action.tolist() == [x["action"] for x in cases]
+
+
+@pytest.mark.parametrize("mode", ["compat", "az"])
+def test_search_at_the_largest_simulation_count(oracle, mode):
+    """9000 simulations per move is the most a 16-bit child index allows (1 + 7 * 9000 nodes per pool).  The pool
+    no longer fits LDS, so the fixed evaluator runs through the lock-step path; visits, move and root value must
+    still be the CPU search's, bit for bit, deep into a pool of 63 001 nodes."""
+    from alphazero_amd.engine import Engine
+    co, rp = oracle
+    sims = 9000
+    pos = [(0, 0, 1)] + _random_positions(rp, co, 5, seed=9000, max_plies=10)
+    boards = np.array([(p[0], p[1]) for p in pos], dtype=np.uint64)
+    players = np.array([p[2] for p in pos], dtype=np.int8)
+    eng = Engine(max_games=len(pos), max_sims=sims)
+    try:
+        with pytest.raises(Exception, match="max_sims"):
+            Engine(max_games=1, max_sims=sims + 1)
+        visits, action, rootv, stats = eng.search(boards, players, eng.params(sims, 1.4, evaluator="hash_f32", mode=mode))
+    finally:
+        eng.close()
+    for i, (b1, b2, player) in enumerate(pos):
+        if mode == "compat":
+            a, v, st = co.compat_search(b1, b2, player, sims, 1.4, "hash_f32")
+            assert rootv[i] == st.root_value
+        else:
+            a, v, _ = co.az_search(b1, b2, player, sims, 1.4, "hash_f32")
+        assert visits[i].tolist() == v and int(action[i]) == a, i
+    assert stats["sims"] == sims * len(pos)
