@@ -850,6 +850,10 @@ int nnb_debug_activations(nnb_engine *e, int weight_set, void *stream, int layer
 int nnb_search(nnb_engine *e, void *stream, const nnb_search_params *params, int32_t n,
                const uint64_t *root_colour_boards, const int8_t *root_players, const int8_t *side_players,
                const float *root_noise, int32_t *visits_out, int8_t *action_out, double *root_value_out, nnb_round_stats *stats_out) {
+    if (e && params && n == 0) {                         // no roots: a no-op like the other entry points
+        if (stats_out) memset(stats_out, 0, sizeof *stats_out);
+        return NNB_OK;
+    }
     int rc = check_params(e, params, n);
     if (rc) return rc;
     if (!root_colour_boards || !root_players) return fail(NNB_ERR_ARG, "root boards / players is null");

@@ -280,7 +280,7 @@ int nnb_minimax(void *stream, int32_t n, const uint64_t *colour_boards, const in
  * root_noise [n,7] (AZ mode, may be NULL): noise mixed into the root priors with weight
  * dirichlet_eps; when NULL and dirichlet_alpha > 0 the engine draws Dirichlet(alpha)
  * noise itself from its counter-based RNG (see nnb_dirichlet_noise).
- * stats_out (host pointer, may be NULL) is filled when the call returns.  Synchronous. */
+ * stats_out (host pointer, may be NULL) is filled when the call returns.  n = 0 is a no-op.  Synchronous. */
 int nnb_search(nnb_engine *engine, void *stream, const nnb_search_params *params, int32_t n,
                const uint64_t *root_colour_boards, const int8_t *root_players,
                const int8_t *side_players, const float *root_noise, int32_t *visits_out, int8_t *action_out,

@@ -285,6 +285,10 @@ def test_search_terminal_and_single_sim_roots(engine, oracle):
     assert visits[0].tolist() == [0] * 7 and int(action[0]) == -1
     a, v, _ = co.compat_search(won[0], won[1], 2, 50, 1.4, "const")
     assert a is None and v == [0] * 7
+    # no roots at all: a no-op, as for the rule and network entry points
+    visits, action, rootv, stats = engine.search(np.zeros((0, 2), dtype=np.uint64), np.zeros(0, dtype=np.int8),
+                                                 engine.params(50, 1.4, evaluator="const"))
+    assert visits.shape == (0, 7) and action.shape == (0,) and rootv.shape == (0,) and stats["sims"] == 0
     # one simulation only expands the root: children exist, all with zero visits, move 0
     visits, action, _, _ = engine.search(np.zeros((1, 2), dtype=np.uint64), np.array([1], dtype=np.int8),
                                          engine.params(1, 1.4, evaluator="hash_q8"))
