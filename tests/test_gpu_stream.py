@@ -155,3 +155,27 @@ def test_weights_reloaded_between_calls_of_a_stream(gpu):
         assert (ref_a[late["game_id"]]["plies"].tobytes() != late["plies"].tobytes())      # the weights matter
     finally:
         eng.close()
+
+
+def test_stream_with_the_evaluation_cache_plays_the_same_games(gpu):
+    """NNB_FLAG_EVAL_CACHE on a stream: a slot's table is emptied when the slot takes its next game, so records
+    still equal the uncached plain round's byte for byte while fewer leaves reach the network."""
+    from alphazero_amd.engine import Engine, trajectories_to_numpy
+    from alphazero_amd.network import seeded_state_dict
+    from alphazero_amd.selfplay import random_openings
+    slots, sims = 40, 32
+    eng = Engine(max_games=slots, max_sims=sims, eval_cache_slots=256)
+    try:
+        eng.load_state_dict(seeded_state_dict(0))
+        sb, sp = random_openings(eng, 300, 5, seed=8)
+        cached = eng.params(sims, 1.4, evaluator="net", mode="compat", eval_cache=True)
+        rec, totals = _stream_records(eng, cached, calls=3, per_call=60, start_boards=sb, start_players=sp)
+        assert totals["games"] > slots
+        n = int(rec["game_id"].max()) + 1
+        sel = np.arange(n) % 300
+        traj, st = eng.selfplay_round(n, eng.params(sims, 1.4, evaluator="net", mode="compat"), start_boards=sb[sel], start_players=sp[sel])
+        ref = trajectories_to_numpy(traj)
+        assert rec.tobytes() == ref[rec["game_id"]].tobytes()
+        assert st["cache_hits"] == 0
+    finally:
+        eng.close()
