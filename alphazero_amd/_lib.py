@@ -72,6 +72,7 @@ SIGNATURES = {
                                      _P, C.POINTER(RoundStats)]),
     "nnb_selfplay_stream": (C.c_int, [_P, _P, C.POINTER(SearchParams), C.c_int32, C.c_int32, C.c_int32, _P, _P,
                                       C.c_int32, _P, _P, C.c_int32, C.POINTER(RoundStats)]),
+    "nnb_trajectory_samples": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     "nnb_profile_enable": (C.c_int, [_P, C.c_int]),
     "nnb_profile_reset": (C.c_int, [_P]),
     "nnb_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -30,6 +30,8 @@ hipError_t prepare_tree_step();
 void launch_tree_fused(hipStream_t st, const EngineDev &e, const SearchDev &p, size_t lds_bytes);
 void launch_readout(hipStream_t st, const EngineDev &e, const SearchDev &p, int32_t *visits_out,
                     int8_t *action_out, double *root_value_out, const RoundDev *round);
+void launch_trajectory_samples(hipStream_t st, int n, const nnb_trajectory *rec, const int32_t *ply_offsets, float *planes,
+                               float *probs, float *z);
 void launch_selfplay_init(hipStream_t st, const EngineDev &e, const RoundDev &round);
 void launch_turnover(hipStream_t st, const EngineDev &e, const SearchDev &p, const RoundDev &round, int make_noise,
                      const GameSpan *span = nullptr);

@@ -1020,6 +1020,16 @@ int nnb_selfplay_stream(nnb_engine *e, void *stream, const nnb_search_params *pa
     return NNB_OK;
 }
 
+int nnb_trajectory_samples(void *stream, int32_t n, const nnb_trajectory *records, const int32_t *ply_offsets,
+                            float *planes_out, float *probs_out, float *z_out) {
+    if (n < 0) return fail(NNB_ERR_ARG, "n < 0");
+    if (n == 0) return NNB_OK;
+    if (!records || !ply_offsets || !planes_out || !probs_out || !z_out) return fail(NNB_ERR_ARG, "null pointer");
+    launch_trajectory_samples(static_cast<hipStream_t>(stream), n, records, ply_offsets, planes_out, probs_out, z_out);
+    HIP_TRY(hipGetLastError());
+    return NNB_OK;
+}
+
 int nnb_dirichlet_noise(void *stream, int32_t n, uint64_t seed, const int32_t *game_ids, const int32_t *move_indices,
                         const uint8_t *legal_masks, double alpha, float *noise_out) {
     if (n < 0) return fail(NNB_ERR_ARG, "n < 0");

@@ -53,6 +53,37 @@ __global__ void encode_planes_kernel(int n, const u64 *__restrict__ side, float 
     planes[i] = (float)((bits >> (col * 7 + (5 - row))) & 1);
 }
 
+// Finished records -> per-ply training samples, one thread per (record, ply): planes from the mover's side
+// (agent_code.py:84-88), the root visit distribution (visits / their sum, the division in float64 as numpy does
+// it, agent_code.py:226-232), and z = +1 / -1 / 0 as the mover of that ply went on to win / lose / draw
+// (agent_code.py:259-266).  ply_offsets[i] = plies of the records before record i.
+__global__ void trajectory_samples_kernel(int n, const nnb_trajectory *__restrict__ rec,
+                                          const int32_t *__restrict__ ply_offsets, float *__restrict__ planes,
+                                          float *__restrict__ probs, float *__restrict__ z) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * kMaxPlies) return;
+    const int g = i / kMaxPlies, k = i - g * kMaxPlies;
+    const nnb_trajectory *t = rec + g;
+    int len = t->length;
+    len = len < 0 ? 0 : (len > kMaxPlies ? kMaxPlies : len);
+    if (k >= len) return;
+    const nnb_ply *ply = &t->plies[k];
+    const size_t o = (size_t)ply_offsets[g] + k;
+    const int me = ply->player == 2 ? 2 : 1;
+    const u64 mine = ply->colour_boards[me - 1], theirs = ply->colour_boards[2 - me];
+    float *pl = planes + o * 84;
+    for (int cell = 0; cell < 42; ++cell) {
+        const int row = cell / 7, col = cell - row * 7, bit = col * 7 + (5 - row);
+        pl[cell] = (float)((mine >> bit) & 1);
+        pl[42 + cell] = (float)((theirs >> bit) & 1);
+    }
+    double sum = 0.0;
+    for (int c = 0; c < 7; ++c) sum += (double)ply->visits[c];
+    for (int c = 0; c < 7; ++c) probs[o * 7 + c] = sum > 0.0 ? (float)((double)ply->visits[c] / sum) : 0.f;
+    const int res = t->result;
+    z[o] = (res == 1 || res == -1) ? (((res == 1) == (me == 1)) ? 1.f : -1.f) : 0.f;
+}
+
 // mcts.py:29 element-wise, float64.
 __global__ void ucb_scores_kernel(int n, const double *__restrict__ value, const int32_t *__restrict__ visits,
                                   const int32_t *__restrict__ parent_visits, double c_puct,
@@ -1065,6 +1096,12 @@ void launch_game_ops(hipStream_t st, int n, const u64 *in, const int8_t *players
 void launch_encode_planes(hipStream_t st, int n, const u64 *side, float *planes) {
     if (n <= 0) return;
     encode_planes_kernel<<<cdiv(n * 84, 256), 256, 0, st>>>(n, side, planes);
+}
+
+void launch_trajectory_samples(hipStream_t st, int n, const nnb_trajectory *rec, const int32_t *ply_offsets, float *planes,
+                               float *probs, float *z) {
+    if (n <= 0) return;
+    trajectory_samples_kernel<<<cdiv(n * kMaxPlies, 256), 256, 0, st>>>(n, rec, ply_offsets, planes, probs, z);
 }
 
 void launch_ucb_scores(hipStream_t st, int n, const double *value, const int32_t *visits,

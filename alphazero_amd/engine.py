@@ -298,6 +298,23 @@ class Engine:
         records = self._ring[self._finished_ring[order].long()]
         return records, st
 
+    def trajectory_samples(self, records: torch.Tensor):
+        """Device records [n, 1376] uint8 -> per-ply training samples on the device (nnb_trajectory_samples):
+        (planes float32 [P,2,6,7] from the mover's side, visit distributions float32 [P,7], z float32 [P]),
+        P = total plies, samples ordered by record then ply."""
+        rec = records.to(self.device).contiguous()
+        n = rec.shape[0]
+        lengths = rec[:, :4].contiguous().view(torch.int32).reshape(n).clamp(0, 42)
+        offsets = (torch.cumsum(lengths, 0) - lengths).to(torch.int32)
+        total = int(lengths.sum().item()) if n else 0
+        planes = torch.empty((total, 2, 6, 7), dtype=torch.float32, device=self.device)
+        probs = torch.empty((total, 7), dtype=torch.float32, device=self.device)
+        z = torch.empty((total,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.nnb_trajectory_samples(self._stream(), n, _ptr(rec), _ptr(offsets), _ptr(planes), _ptr(probs),
+                                                  _ptr(z)), "nnb_trajectory_samples")
+        return planes, probs, z
+
     def dirichlet_noise(self, seed: int, game_ids, move_indices, legal_masks, alpha: float) -> np.ndarray:
         """The root noise the engine draws for (seed, game id, move index); float32 [n,7]."""
         gi = self._dev(np.asarray(game_ids, dtype=np.int32), torch.int32)

@@ -157,6 +157,18 @@ def self_play_samples(agent, num_games) -> List[tuple]:
     return out
 
 
+def self_play_sample_tensors(agent, num_games, first_game_id: int = 0):
+    """self_play_samples without the host loop: the games are played and their per-ply samples built on the
+    device (nnb_trajectory_samples); returns (planes [P,2,6,7], visit distributions [P,7], z [P]) as device
+    tensors in the order self_play_samples lists them - what ConnectFourDataset (data_module.py:13-27) stacks."""
+    num_games = int(num_games)
+    eng = agent.engine(min(max(num_games, 1), MAX_CONCURRENT_GAMES))
+    params = eng.params(agent.num_simulations, agent.c_puct, evaluator=agent.evaluator, mode="compat",
+                        eval_cache=getattr(agent, "eval_cache", False))
+    traj, _ = eng.selfplay_round(num_games, params, first_game_id=first_game_id)
+    return eng.trajectory_samples(traj)
+
+
 def train_alphazero(time_limit, num_self_play_games=100, use_gpu=True, load_model=True):
     """Entry point kept for import compatibility (train_alpha_zero.py:57-119).  The self-play half
     runs on the engine; the Lightning training half is not part of this package."""

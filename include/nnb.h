@@ -348,6 +348,19 @@ int nnb_selfplay_stream(nnb_engine *engine, void *stream, const nnb_search_param
                         const int8_t *start_players, int32_t n_starts, nnb_trajectory *record_ring,
                         int32_t *finished_ring, int32_t ring_len, nnb_round_stats *stats_out);
 
+/* Records -> per-ply training samples on the device, what AlphaZeroAgent.self_play keeps per move
+ * (agent_code.py:254-267: state, MCTS visit distribution, value target) in the form ConnectFourDataset
+ * stacks (data_module.py:13-27).  For ply k < length of record i, sample s = ply_offsets[i] + k:
+ *   planes_out[s]  float32 [2,6,7]: plane 0 the mover's stones, plane 1 the rival's, row 0 = top
+ *                  (preprocess, agent_code.py:76-89), the position BEFORE the move;
+ *   probs_out[s]   float32 [7]: root visit counts / their sum (agent_code.py:226-232; zeros if no visits);
+ *   z_out[s]       float32: +1 if the mover of that ply won the game, -1 if it lost, 0 for a draw or an
+ *                  unfinished record (agent_code.py:259-266).
+ * ply_offsets [n] (device) = number of plies in the records before record i (exclusive prefix sum of the
+ * lengths, which the caller computes); the outputs hold sum(length) samples.  Asynchronous on `stream`. */
+int nnb_trajectory_samples(void *stream, int32_t n, const nnb_trajectory *records, const int32_t *ply_offsets,
+                           float *planes_out, float *probs_out, float *z_out);
+
 /* The Dirichlet(alpha) root noise the engine draws for (seed, game id, move index) over the
  * legal columns of each row: out [n,7], zero on illegal columns, rows sum to 1.  Exposed so a
  * caller (or a test) can reproduce exactly what an AZ-mode search mixed into its root.

@@ -214,3 +214,42 @@ def test_weights_file_round_trip_into_the_engine(torch_mod, tmp_path, monkeypatc
     monkeypatch.setattr(agent_mod, "MODEL_PATH", str(tmp_path / "nothing.pth"))
     with pytest.raises(FileNotFoundError):
         load_agent_model(reader)
+
+
+def test_per_ply_samples_built_on_the_device_equal_the_host_loop(torch_mod):
+    """nnb_trajectory_samples against the host loop of self_play_samples on the same records: planes, visit
+    distributions and value targets, bit for bit, over games of every outcome (wins of both colours, draws are
+    rare: an unfinished record is forged to cover z = 0) and an empty record."""
+    from alphazero_amd.engine import Engine, trajectories_to_numpy
+    from alphazero_amd.selfplay import _planes, random_openings
+    torch = torch_mod
+    eng = Engine(max_games=64, max_sims=24)
+    try:
+        sb, sp = random_openings(eng, 200, 6, seed=2)
+        traj, _ = eng.selfplay_round(200, eng.params(24, 1.4, evaluator="hash_f32"), start_boards=sb, start_players=sp)
+        rec = trajectories_to_numpy(traj).copy()
+        assert {1, -1} <= set(rec["result"].tolist())
+        rec["result"][5] = 2                                        # a cut-off game: z = 0 for all its plies
+        rec["length"][7] = 0                                        # a game that started finished: no samples
+        dev = torch.from_numpy(rec.view(np.uint8).reshape(200, -1)).cuda()
+        planes, probs, z = eng.trajectory_samples(dev)
+        P = int(rec["length"].sum())
+        assert planes.shape == (P, 2, 6, 7) and probs.shape == (P, 7) and z.shape == (P,)
+        planes, probs, z = planes.cpu().numpy(), probs.cpu().numpy(), z.cpu().numpy()
+        s = 0
+        for r in rec:
+            res = int(r["result"])
+            for i in range(int(r["length"])):
+                ply = r["plies"][i]
+                me = int(ply["player"])
+                vis = ply["visits"].astype(np.float64)
+                want = (vis / vis.sum()).astype(np.float32)
+                assert planes[s].tobytes() == _planes(int(ply["colour_boards"][0]), int(ply["colour_boards"][1]), me).tobytes()
+                assert probs[s].tobytes() == want.tobytes()
+                assert z[s] == (0 if res in (0, 2) else (1 if (res == 1) == (me == 1) else -1))
+                s += 1
+        assert s == P
+        e = eng.trajectory_samples(dev[:0])
+        assert e[0].shape[0] == 0 and e[2].shape[0] == 0
+    finally:
+        eng.close()
