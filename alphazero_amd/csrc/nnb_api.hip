@@ -58,6 +58,24 @@ struct Carver {
     }
 };
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel on a device, not to an engine: one high-water
+// mark per device for the whole process, only ever raised (engines and nnb_search_static share the kernel).
+constexpr int kMaxDevices = 64;
+size_t g_fused_lds[kMaxDevices] = {};
+std::mutex g_fused_lds_mutex;
+
+int ensure_tree_fused_lds(size_t lds) {
+    int device = -1;
+    HIP_TRY(hipGetDevice(&device));
+    if (device < 0 || device >= kMaxDevices) return fail(NNB_ERR_ARG, "device ordinal %d out of range", device);
+    std::lock_guard<std::mutex> lock(g_fused_lds_mutex);
+    if (lds > g_fused_lds[device]) {
+        HIP_TRY(prepare_tree_fused(lds));
+        g_fused_lds[device] = lds;
+    }
+    return NNB_OK;
+}
+
 struct ProfClass {
     hipEvent_t start[kProfSamples], stop[kProfSamples];
     int used = 0;
@@ -76,7 +94,6 @@ struct nnb_engine {
     std::vector<int> weights_loaded;
     int32_t *host_counters = nullptr;      // pinned, 16 ints
     unsigned long long *host_stats = nullptr;   // pinned, 8 u64
-    size_t fused_lds_prepared = 0;
     hipStream_t side_stream = nullptr;     // second forward pass of a two-network arena
     hipEvent_t fork_event = nullptr, join_event = nullptr;
     // nnb_selfplay_stream: games stay seated between calls
@@ -430,10 +447,7 @@ int run_move(nnb_engine *e, hipStream_t st, const nnb_search_params &p, int32_t 
         if (!fits_lds)
             return fail(NNB_ERR_ARG, "sims = %d needs %zu bytes of LDS for the fused tree kernel (limit %zu)",
                         p.sims, lds, kFusedLdsLimit);
-        if (lds > e->fused_lds_prepared) {
-            HIP_TRY(prepare_tree_fused(lds));
-            e->fused_lds_prepared = lds;
-        }
+        if (int rc = ensure_tree_fused_lds(lds)) return rc;
         { ProfScope ps(e, 0, st); launch_tree_fused(st, d, sd, lds); }
         *steps += 1;
     }
@@ -479,7 +493,6 @@ __global__ void debug_act_kernel(int kind, const void *src, const float *src2, c
 constexpr int kStaticRoots = NNB_STATIC_MAX_ROOTS, kStaticSims = NNB_STATIC_MAX_SIMS;
 constexpr size_t kStaticPool = 8;                   // root + its children: all the fused kernel hands to the readout
 constexpr size_t kStaticBytes = 512 * 1024;
-constexpr int kMaxDevices = 64;
 
 }  // namespace
 
@@ -499,13 +512,15 @@ struct StaticState {
     bool ready = false;
     void *ptr = nullptr;                            // device address of `scratch` on this GPU
     EngineDev dev;
-    size_t fused_lds_prepared = 0;
 };
 StaticState g_static[kMaxDevices];
 std::mutex g_static_mutex;
 
 // First call on a device: resolve the array's address there, lay the search state out in it, clear it and
 // fill the log table (values from the host's libm, handed over as kernel arguments: no copy, no allocation).
+// The set-up is enqueued on the caller's stream and WAITED FOR before the state counts as ready, so a later
+// call on any other stream finds the table filled; a first call under stream capture is refused (its set-up
+// would only be recorded into the graph, not run).
 int static_state(hipStream_t st, StaticState **out) {
     int device = -1;
     HIP_TRY(hipGetDevice(&device));
@@ -513,6 +528,11 @@ int static_state(hipStream_t st, StaticState **out) {
     StaticState &s = g_static[device];
     std::lock_guard<std::mutex> lock(g_static_mutex);
     if (!s.ready) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        HIP_TRY(hipStreamIsCapturing(st, &cap));
+        if (cap != hipStreamCaptureStatusNone)
+            return fail(NNB_ERR_STATE, "the first nnb_search_static call on a device sets its search state up and must not "
+                        "run under stream capture: call it once eagerly first");
         void *ptr = nullptr;
         HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
         if (!ptr || reinterpret_cast<uintptr_t>(ptr) % kAlign) return fail(NNB_ERR_HIP, "bad address for the static search state");
@@ -528,6 +548,7 @@ int static_state(hipStream_t st, StaticState **out) {
             store_log_chunk_kernel<<<1, 256, 0, st>>>(s.dev.log_table + base, chunk, n);
         }
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
         s.ptr = ptr;
         s.ready = true;
     }
@@ -1082,10 +1103,8 @@ int nnb_search_static(void *stream, const nnb_search_params *p, int32_t n, const
     const size_t pool_nodes = 1 + 7 * (size_t)p->sims;
     const size_t lds = pool_nodes * sizeof(Node) + (az ? pool_nodes * sizeof(float) : (size_t)(p->sims + 2) * sizeof(double));
     if (lds > kFusedLdsLimit) return fail(NNB_ERR_ARG, "sims = %d needs %zu bytes of LDS (limit %zu)", p->sims, lds, kFusedLdsLimit);
-    if (lds > s->fused_lds_prepared) {
-        HIP_TRY(prepare_tree_fused(lds));
-        s->fused_lds_prepared = lds;
-    }
+    rc = ensure_tree_fused_lds(lds);
+    if (rc) return rc;
     EngineDev d = s->dev;                   // every pointer in it derives from the address hipGetSymbolAddress returned
     d.n_games = n;
     launch_search_init(st, d, reinterpret_cast<const u64 *>(root_colour_boards), root_players, side_players,

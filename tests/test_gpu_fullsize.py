@@ -79,12 +79,62 @@ def test_config2_4096_games_200_sims_network(gpu, oracle):
     _replay_and_check(co, rec, 200, sample=[0, 4095])
     assert stats["games"] == 4096 and stats["plies"] == 4096 * n and stats["sims"] == 4096 * n * 200
     assert stats["net_leaves"] + stats["terminal_hits"] == stats["sims"]
-    # the opening move agrees with the CPU search driven by the CPU float32 network
+    # the whole game, move for move and visit vector for visit vector, equals the CPU search (the reference's
+    # rule, oracle/c4_oracle.c) driven by the CPU float32 network (train_alpha_zero.py:41-45)
     from alphazero_amd.game import bits_to_board
     net = rp.make_net_evaluator(rp.seeded_state_dict(0))
-    a, v, _ = co.compat_search(0, 0, 1, 200, 1.4, lambda me, opp: net(bits_to_board(me, opp), 1))
-    assert int(first["plies"]["action"][0]) == a
-    print("opening visits: device", first["plies"]["visits"][0].tolist(), "cpu", v)
+    b1 = b2 = 0
+    player = 1
+    for k in range(n):
+        a, v, _ = co.compat_search(b1, b2, player, 200, 1.4, lambda me, opp: net(bits_to_board(me, opp), 1))
+        assert v == first["plies"]["visits"][k].tolist() and a == int(first["plies"]["action"][k]), k
+        _, b1, b2 = co.drop(b1, b2, player, a)
+        player = 3 - player
+    assert co.lib().orc_is_terminal(b1, b2)
+
+
+def test_benchmark_stream_4096_slots_two_chains_equals_plain_round_and_cpu_search(gpu, oracle):
+    """The workload bench.py times, at its size: 4096 slots, 200 sims/move, the seed-0 network in float32-faithful
+    arithmetic, games from 4 random opening plies, an endless stream on the default two chains.  Two steps of the
+    stream; every record must equal, byte for byte, the record a plain round writes for the same game id and start
+    position, and the first plies of four sampled games must equal the CPU search (moves and visit vectors)."""
+    import torch
+    from alphazero_amd.engine import Engine, trajectories_to_numpy
+    from alphazero_amd.game import bits_to_board
+    from alphazero_amd.selfplay import random_openings
+    co, rp = oracle
+    slots, sims, n_starts = 4096, 200, 16384
+    eng = Engine(max_games=slots, max_sims=sims)
+    assert eng.precision == "f32s"
+    try:
+        eng.load_state_dict(rp.seeded_state_dict(0))
+        sb, sp = random_openings(eng, n_starts, 4, seed=1234)
+        prm = eng.params(sims, 1.4, evaluator="net", mode="compat")
+        recs = []
+        for i in range(2):
+            r, st = eng.selfplay_stream(slots, prm if i == 0 else None, restart=(i == 0), start_boards=sb, start_players=sp)
+            assert st["chains"] == 2 and st["games"] >= slots
+            recs.append(trajectories_to_numpy(r).copy())
+        rec = np.concatenate(recs)
+        ids = rec["game_id"]
+        assert len(set(ids.tolist())) == len(ids) and (rec["result"] != 2).all()
+        n = int(ids.max()) + 1
+        assert n <= n_starts
+        traj, st = eng.selfplay_round(n, prm, start_boards=sb[:n], start_players=sp[:n])
+        ref = trajectories_to_numpy(traj)
+        assert rec.tobytes() == ref[ids].tobytes()
+    finally:
+        eng.close()
+    _replay_and_check(co, rec, sims, start_players=sp[ids], sample=range(0, len(rec), 97), start_boards=sb[ids])
+    net = rp.make_net_evaluator(rp.seeded_state_dict(0))
+    for i in (0, len(rec) // 3, 2 * len(rec) // 3, len(rec) - 1):
+        r = rec[i]
+        b1, b2, player = int(sb[ids[i]][0]), int(sb[ids[i]][1]), int(sp[ids[i]])
+        for k in range(min(3, int(r["length"]))):
+            a, v, _ = co.compat_search(b1, b2, player, sims, 1.4, lambda me, opp: net(bits_to_board(me, opp), 1))
+            assert v == r["plies"]["visits"][k].tolist() and a == int(r["plies"]["action"][k]), (i, k)
+            _, b1, b2 = co.drop(b1, b2, player, a)
+            player = 3 - player
 
 
 def test_config4_tree_only_800_sims_rollouts(gpu, oracle):

@@ -17,7 +17,7 @@ def rp():
     return ref_port
 
 
-@pytest.mark.parametrize("precision", ["f16", "f32"])
+@pytest.mark.parametrize("precision", ["f32s", "f16", "f32"])
 @pytest.mark.parametrize("mode", ["compat", "az"])
 def test_fused_and_separate_heads_agree(rp, precision, mode):
     from alphazero_amd.engine import Engine, trajectories_to_numpy

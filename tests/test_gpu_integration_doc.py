@@ -31,7 +31,7 @@ def test_documented_ctypes_stub_runs_and_matches_the_engine():
     board[5][3] = 1
     action, visits = ns["search"](handle, board, 2, 2, 64, 1.4)
     action_s, visits_s = ns["search"](handle, board, 2, 1, 64, 1.4)     # the agent still looks from colour 1
-    eng = Engine(max_games=1, max_sims=64, precision="f16")             # the stub's Config picks half inputs
+    eng = Engine(max_games=1, max_sims=64, precision="f32s")            # the stub's Config asks for float32-faithful arithmetic
     try:
         eng.load_state_dict(model.state_dict())
         root, mover = np.array([[1 << (3 * 7), 0]], dtype=np.uint64), np.array([2], dtype=np.int8)

@@ -107,3 +107,49 @@ def test_static_search_refuses_what_does_not_fit():
         assert rc == 0                                           # an empty call is a no-op
     finally:
         eng.close()
+
+
+def test_small_static_search_does_not_shrink_the_engines_lds_budget():
+    """The fused tree kernel's dynamic-LDS ceiling is a property of the kernel on the device: an engine raises it
+    for an 800-simulation search, a small static search must not lower it again for the engine's next one."""
+    import torch
+    from alphazero_amd import _lib
+    from alphazero_amd.engine import Engine
+    lib = _lib.load()
+    eng = Engine(max_games=8, max_sims=800, precision="f16")
+    try:
+        pos = _positions(8, seed=31)
+        boards = np.array([(p[0], p[1]) for p in pos], dtype=np.uint64)
+        players = np.array([p[2] for p in pos], dtype=np.int8)
+        big = eng.params(800, 1.4, evaluator="hash_q8", mode="az")
+        first = eng.search(boards, players, big)
+        rc, v, a, _ = _static_search(lib, torch, eng.params(20, 1.4, evaluator="hash_q8"), boards, players)
+        assert rc == 0, lib.nnb_last_error()
+        again = eng.search(boards, players, big)
+        assert (first[0] == again[0]).all() and (first[0].sum(axis=1) == 799).all()
+    finally:
+        eng.close()
+
+
+def test_static_search_from_two_streams():
+    """A call on a second stream right after a call on the first: the one-time set-up (log table) was waited for
+    by the first call, so the second stream finds it filled whatever it is ordered against."""
+    import torch
+    from alphazero_amd import _lib
+    from alphazero_amd.engine import Engine
+    lib = _lib.load()
+    eng = Engine(max_games=64, max_sims=100, precision="f16")
+    try:
+        pos = _positions(64, seed=77)
+        boards = np.array([(p[0], p[1]) for p in pos], dtype=np.uint64)
+        players = np.array([p[2] for p in pos], dtype=np.int8)
+        prm = eng.params(100, 1.4, evaluator="hash_f32")
+        want = eng.search(boards, players, prm)
+        for st in (torch.cuda.Stream(), torch.cuda.Stream()):
+            torch.cuda.synchronize()
+            with torch.cuda.stream(st):
+                rc, v, a, rv = _static_search(lib, torch, prm, boards, players)
+            assert rc == 0, lib.nnb_last_error()
+            assert (v == want[0]).all() and (a == want[1]).all() and (rv == want[2]).all()
+    finally:
+        eng.close()
