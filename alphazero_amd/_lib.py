@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libnnb.so")
+# NNB_LIB selects another build of the same ABI (tools/build_variants.py: timing experiments)
+LIB_PATH = os.environ.get("NNB_LIB") or os.path.join(HERE, "libnnb.so")
 
 MODE_COMPAT, MODE_AZ = 0, 1
 EVAL_NET, EVAL_CONST, EVAL_HASH_Q8, EVAL_HASH_F32, EVAL_ROLLOUT = 0, 1, 2, 3, 4

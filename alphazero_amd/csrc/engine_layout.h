@@ -99,6 +99,7 @@ constexpr int kRefills = 16;    // index into EngineDev::counters; entries 0..15
 constexpr int kLive = 17;       // slots that still hold a game (kept through a whole round)
 constexpr int kEndlessGames = 1 << 30;   // total_games at or above this: an endless stream of games (nnb_selfplay_stream)
 constexpr int kSeatTries = 4096;         // finished start positions in a row after which a slot of a stream gives up
+constexpr int kSyncErr = 19;    // waits between blocks of the split linear layer that ran out (results invalid if != 0)
 constexpr int kFinished = 18;   // games finished since the round was set up (directly behind kLive: read together)
 
 // Games [first, end) and the leaf batch they file their leaves in (-1: by the root mover's weight set).

@@ -11,6 +11,8 @@
 namespace nnb {
 
 struct HeadsDev {
+    const float *q;         // non-null: [rows][8 heads][32] per-column-tile partial dot products of the heads with
+                            // ReLU(linear layer) (written by the split linear layer's last step); x0, x1, hw unused
     const float *x0;        // [rows][1024] linear-layer output, or the first split-K partial sum
     const float *x1;        // second partial sum, or null when x0 is already bias + ReLU
     const float *fc_bias;   // [1024] added before the ReLU when x1 != null
@@ -54,6 +56,30 @@ __device__ __forceinline__ float heads_dot(const float4 (&xv)[4], const float4 *
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     return s;
+}
+
+// Heads from the per-column-tile partial sums q[head][tile] (tile = 32 consecutive columns of the linear layer's
+// output).  A head's 32 partial sums are added as a balanced tree over the tile index: first tile ^ 16, then ^ 8,
+// ^ 4, ^ 2, ^ 1 (the same shape as the sum over a tile's 32 columns that produced each q), then the head's bias.
+// Every lane returns all 8 sums.
+__device__ __forceinline__ void heads_z_from_q(const float *qrow, const float *hb, int lane, float (&z)[8]) {
+    float4 v = reinterpret_cast<const float4 *>(qrow)[lane];       // head lane >> 3, tiles 4 * (lane & 7) .. + 3
+#pragma unroll
+    for (int off = 4; off >= 1; off >>= 1) {                          // tile ^ 16, ^ 8, ^ 4  <->  lane ^ 4, ^ 2, ^ 1
+        v.x += __shfl_xor(v.x, off); v.y += __shfl_xor(v.y, off);
+        v.z += __shfl_xor(v.z, off); v.w += __shfl_xor(v.w, off);
+    }
+    const float s = (v.x + v.z) + (v.y + v.w);                        // tile ^ 2, then tile ^ 1
+#pragma unroll
+    for (int o = 0; o < 8; ++o) z[o] = __shfl(s, 8 * o) + hb[o];
+}
+
+// The value head alone (row 7 of q), same order of additions.
+__device__ __forceinline__ float heads_value_from_q(const float *qrow, const float *hb, int lane) {
+    float v = qrow[7 * 32 + (lane & 31)];
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v + hb[7];
 }
 
 // log-softmax of the 7 policy logits (network.py:48).

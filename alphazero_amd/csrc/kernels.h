@@ -78,6 +78,17 @@ struct NetBuffers {            // activations, channels-last float32
     float *act1_b1, *act2_b1, *act3_b1;   // and its convolution buffers (the two batches run on two streams)
     float *act2_inv, *act3_inv;           // split-operand path: 1 / scale of each board's activations, [G] each
     float *act2_inv_b1, *act3_inv_b1;
+    // split-operand path, last step of the linear layer (fc_split_finish): per-column-tile partial sums of the heads
+    // [G][8][32], the tile the first-arriving K half hands to its partner block ((G + 128) x 1024 floats), the
+    // ticket and flag words of those pairs, a word that counts waits that ran out, and (batch 0 only) the hidden
+    // activations ReLU(linear layer) [G][1024] for nnb_debug_activations
+    float *fcq, *fcq_b1;
+    float *fchand, *fchand_b1;
+    uint32_t *fcsync, *fcsync_b1;
+    int32_t *sync_err;
+    int fc_pairs;              // ticket words per batch (the flag words follow them)
+    int heads_all;             // 1: the linear layer's last step produces all 8 heads, 0: the value head only
+    int write_hidden;          // 1: it also writes the hidden activations to `fc`
     int max_rows;              // G
     int shared_chip;           // 1: another forward pass runs beside this one on a second stream (two chains of a
                                //    self-play round, the two networks of an arena): with 1025..2048 rows the linear
@@ -89,7 +100,12 @@ enum NetStage { NET_CONV0 = 0, NET_CONV2 = 1, NET_CONV4 = 2, NET_FC = 3, NET_HEA
                 // two 128->128 layers stay in LDS), and the same with those activations also copied out
                 NET_CONV_PAIR = 5, NET_CONV_PAIR_MID = 6 };
 
+// Ticket / flag words of the linear layer's block pairs for G rows: the large-batch form pairs (row block of 32..128
+// rows, 256-column block), the small-batch form (32-row tile, 32-column tile) for at most 256 rows.
+constexpr int fc_sync_pairs(int max_rows) { return ((max_rows + 31) / 32 + 8) * 32; }
+
 HeadsDev heads_input_f32(const NetWeights &w, const NetBuffers &b);
+HeadsDev heads_input_split(const NetWeights &w, const NetBuffers &b);
 HeadsDev heads_input_f16(const NetWeights &w, const NetBuffers &b);
 hipError_t prepare_net_kernels();
 void launch_repack(hipStream_t st, const NetWeights &dst, const float *conv0_w, const float *conv0_b,

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadsDev hd, const uint8_t *
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 HeadsDev heads_input_f32(const NetWeights &w, const NetBuffers &b) {
-    return HeadsDev{b.fc, nullptr, nullptr, w.heads_w, w.heads_b, 0};
+    return HeadsDev{nullptr, b.fc, nullptr, nullptr, w.heads_w, w.heads_b, 0};
 }
 
 constexpr int CONV2_NB = 4, CONV4_NB = 2;

@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256) void heads_split_kernel(HeadsDev hd, const uin
 static inline int cdiv16(int a, int b) { return (a + b - 1) / b; }
 
 HeadsDev heads_input_f16(const NetWeights &w, const NetBuffers &b) {
-    return HeadsDev{b.fcpart, b.fcpart + (size_t)b.max_rows * 1024, w.fc_b, w.heads_w, w.heads_b, b.max_rows};
+    return HeadsDev{nullptr, b.fcpart, b.fcpart + (size_t)b.max_rows * 1024, w.fc_b, w.heads_w, w.heads_b, b.max_rows};
 }
 
 constexpr int C2H_NB = 4, C4H_NB = 3;

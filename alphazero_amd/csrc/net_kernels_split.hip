@@ -1011,10 +1011,11 @@ __global__ __launch_bounds__(256, 2) void conv_pair_split_small_kernel(const u64
 // (two 32-column tiles) for all row tiles, so one k-step of 16 is 8 fragment reads from LDS (hi and
 // lo of up to 4 row tiles), 4 weight loads from L2 (hi and lo of 2 column tiles) and up to 24 MFMAs.
 // A slabs of 64 k (128 bytes of hi and 128 of lo per row) go global -> registers four slabs ahead and
-// registers -> LDS two slabs ahead (three LDS buffers of 32 KB, one barrier per slab).  The partial
-// sums leave the kernel in true units (x row scale x weight scale) as part[ksplit][row][1024]; the
-// heads add the halves, the bias and the ReLU.  Block order as in fc_f16_kernel: blocks that share
-// blockIdx % 8 (one XCD) cover 4 row blocks x (4 column blocks x 2 K halves).
+// registers -> LDS two slabs ahead (three LDS buffers of 32 KB, one barrier per slab).  The two K
+// halves of a tile meet in fc_split_finish, which adds them, the bias and the ReLU and reduces the
+// row against the head rows.  Block order as in fc_f16_kernel: blocks that share blockIdx % 8 (one
+// XCD, as blocks are dealt out today: a matter of speed only) cover 4 row blocks x (4 column blocks
+// x 2 K halves), so the two halves of a tile share an L2.
 // ---------------------------------------------------------------------------
 constexpr int FCS_K = 11520, FCS_N = 1024, FCS_BK = 64, FCS_SPLIT = 2;
 constexpr int FCS_ROW_BYTES = 90 * 512;                      // one activation row: 90 cells x (128 hi + 128 lo halves)
@@ -1025,12 +1026,155 @@ constexpr int FCS_BR = 6;                                    // weight fragments
 constexpr int FCS_LROW = 17 * 16;                            // bytes per row in LDS
 constexpr int FCS_LBUF = 128 * FCS_LROW;                     // bytes per buffer
 
+// ---------------------------------------------------------------------------
+// Last step of the linear layer (network.py:46-49 up to the heads' sums), shared by the large- and small-batch
+// forms.  The two blocks that hold the two K halves of one output tile meet here: each draws a ticket; the one
+// that arrives FIRST hands its partial sums (true units) to the other through memory and leaves, the SECOND adds
+// them to its own, adds the bias, applies the ReLU and multiplies the row by the head rows, so that per leaf
+// 8 x 32 (or, under the reference rule, which ignores priors, 32) floats leave the kernel instead of 2 x 1024.
+// The second never waits for a block that has not started: a first arriver is running by construction.
+//
+// Hand-off (blocks may sit on different XCDs, whose L2s are not coherent): the first writes the tile with
+// write-through 16-byte stores in its own register layout (the partner has the same), every storing wave drains
+// its stores, one lane raises the pair's flag to the ticket it drew + 1; the second polls that word relaxed,
+// then ONE agent-scope acquire drops its CU's stale lines before plain loads.  Tickets only grow (two per launch
+// and pair), so nothing has to be cleared between launches: even ticket = first, and the flag the second waits
+// for is its own ticket.
+//
+// A head's dot product over a tile's 32 columns is a balanced tree over the column index (column ^ 16 first, then
+// ^ 8, ^ 4, ^ 2, ^ 1), whatever the batch size or kernel form, and heads_z_from_q adds the 32 tiles the same way.
+// ---------------------------------------------------------------------------
+struct FcFinish {
+    const float *fc_bias;       // [1024]
+    const float *heads_w;       // [8][1024]: policy rows 0..6, value row 7
+    float *q;                   // [rows][8][32]
+    float *hidden;              // [rows][1024] or null
+    float *handoff;             // [(max_rows + 128) * 1024]
+    unsigned *ticket, *flag;    // [pairs] each
+    int32_t *err;               // += 1 when a wait for the partner's tile runs out (results are then invalid)
+    int heads_all;              // 0: the value head only
+};
+
+template <int K>
+__device__ __forceinline__ float lane_xor(float v) {                 // value of lane ^ K, K < 32 (no memory access)
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (K << 10) | 0x1F));
+}
+
+// p[r], r = 0..15: this lane's column of an MFMA tile's 16 rows.  Returns the sum over the 32 columns (lanes of
+// this half wave) of ONE of those rows: r = 8*bit4(m) + 4*bit3(m) + 2*bit2(m) + bit1(m).  Each exchange halves the
+// values a lane carries, so 16 exchanges do what 80 would do by reducing every row in every lane.
+__device__ __forceinline__ float tile_column_sum(const float (&p)[16], int m) {
+    float v8[8], v4[4], v2[2];
+    const bool b4 = m & 16, b3 = m & 8, b2 = m & 4, b1 = m & 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v8[i] = (b4 ? p[8 + i] : p[i]) + lane_xor<16>(b4 ? p[i] : p[8 + i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v4[i] = (b3 ? v8[4 + i] : v8[i]) + lane_xor<8>(b3 ? v8[i] : v8[4 + i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) v2[i] = (b2 ? v4[2 + i] : v4[i]) + lane_xor<4>(b2 ? v4[i] : v4[2 + i]);
+    const float v1 = (b1 ? v2[1] : v2[0]) + lane_xor<2>(b1 ? v2[0] : v2[1]);
+    return v1 + lane_xor<1>(v1);
+}
+
+// acc[i], i = 0..NT-1: tile i covers rows row0 + 32*(i / NU) .. + 31 and column tile tile0 + i % NU (32 columns);
+// on entry the raw accumulators.  `wave` = this wave's index in the block, `ticket` = what the block drew for `pair`
+// (uniform).  hand_base: float offset of the pair's hand-off area (NW * NT * 1024 floats, NW = waves per block).
+template <int NT, int NU, int NW>
+__device__ __forceinline__ void fc_split_finish(f32x16 (&acc)[NT], const FcFinish &fin, const float *__restrict__ a_inv_scale,
+                                                float inv_sw, unsigned ticket, int pair, size_t hand_base, int row0,
+                                                int count, int max_rows, int tile0, int wave, int lane) {
+    const int m = lane & 31, h = lane >> 5;
+    // back to true units with the row's activation scale and the layer's weight scale
+    static_for<NT>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = min(row0 + 32 * (i / NU) + (r & 3) + 8 * (r >> 2) + 4 * h, max_rows - 1);
+            acc[i][r] *= a_inv_scale[row] * inv_sw;
+        }
+    });
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(fin.handoff + hand_base, 0, NW * NT * 1024 * 4, 0x00027000);
+    const int hoff = (wave * NT * 4 * 64 + lane) * 16;                 // + (i * 4 + j) * 1024 bytes
+    if ((ticket & 1u) == 0u) {                                          // first of the pair: hand the tile over and leave
+        static_for<NT>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32x4 v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = __float_as_uint(acc[i][4 * j + c]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rh, hoff + (i * 4 + j) * 1024, 0, 16);    // 16 = sc1: write-through
+            }
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // every storing wave drains its stores ...
+        __syncthreads();
+        if (threadIdx.x == 0)                                           // ... before one lane raises the flag
+            __hip_atomic_store(fin.flag + pair, ticket + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (threadIdx.x == 0) {
+        bool seen = false;
+        for (int spin = 0; spin < (1 << 20); ++spin) {
+            if (__hip_atomic_load(fin.flag + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ticket) { seen = true; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (!seen) atomicAdd(fin.err, 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    // x = ReLU((first half + second half) + bias); additions commute, so which half arrived first does not matter
+    float bias[NU];
+    static_for<NU>([&](auto U) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;
+        bias[u] = fin.fc_bias[(tile0 + u) * 32 + m];
+    });
+    static_for<NT>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rh, hoff + (i * 4 + j) * 1024, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[i][4 * j + c] = fmaxf((acc[i][4 * j + c] + __uint_as_float(v[c])) + bias[i % NU], 0.f);
+        }
+    });
+    if (fin.hidden) {
+        static_for<NT>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + 32 * (i / NU) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < count) fin.hidden[(size_t)row * FCS_N + (tile0 + i % NU) * 32 + m] = acc[i][r];
+            }
+        });
+    }
+    // heads: per (row, head, column tile) the tree sum over the tile's 32 columns of x * head weight
+    const int rsel = ((m >> 4) & 1) * 8 + ((m >> 3) & 1) * 4 + ((m >> 2) & 1) * 2 + ((m >> 1) & 1);   // row this lane ends up with
+    const int rrow = (rsel & 3) + 8 * (rsel >> 2) + 4 * h;
+    for (int o = fin.heads_all ? 0 : 7; o < 8; ++o) {
+        float hw[NU];
+        static_for<NU>([&](auto U) __attribute__((always_inline)) {
+            constexpr int u = decltype(U)::value;
+            hw[u] = fin.heads_w[o * FCS_N + (tile0 + u) * 32 + m];
+        });
+        static_for<NT>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[r] = acc[i][r] * hw[i % NU];
+            const float sum = tile_column_sum(p, m);
+            const int row = row0 + 32 * (i / NU) + rrow;
+            if (!(m & 1) && row < count) fin.q[(size_t)row * 256 + o * 32 + tile0 + i % NU] = sum;
+        });
+    }
+}
+
 // ABL (timing experiments only, 0 in the product): 1 no activation loads, 2 no weight loads, 4 no LDS
 // staging writes, 8 no fragment reads.
 template <int MTR, int BR, int ABL = 0>
 __device__ __forceinline__ void fc_split_tile(const u32x4 *__restrict__ a, const float *__restrict__ a_inv_scale,
                                               const u32x4 *__restrict__ wph, const u32x4 *__restrict__ wpl,
-                                              const SplitScales *__restrict__ sc, float *__restrict__ part, int count,
+                                              const SplitScales *__restrict__ sc, const FcFinish &fin, int count,
                                               int max_rows, unsigned char *lds, int mbx) {
     const int bid = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, m = lane & 31, h = lane >> 5;
@@ -1054,11 +1198,14 @@ __device__ __forceinline__ void fc_split_tile(const u32x4 *__restrict__ a, const
     // Addresses are a uniform base (scalar registers, advanced per slab / k-step) plus a per-lane 32-bit offset
     // that never changes.  Staging: chunk C of a thread is row 16C + tid/16, piece tid%16 (0-7 hi, 8-15 lo).
     const int prow = tid >> 4, pq = tid & 15;
-    // (buffer loads: resource = the whole array, scalar offset, per-lane offset, immediate - no 64-bit address math)
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a), 0, max_rows * FCS_ROW_BYTES, 0x00027000);
+    // (buffer loads: resource = this block's rows - the base is advanced to row0 in 64-bit arithmetic, so the 32-bit
+    // offsets below stay inside one row block however many rows the array has -, scalar offset, per-lane offset)
+    const int rows_here = min(max_rows - row0, 32 * MTR);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char *>(reinterpret_cast<const unsigned char *>(a) + (size_t)row0 * FCS_ROW_BYTES), 0,
+        rows_here * FCS_ROW_BYTES, 0x00027000);
     const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(wph), 0, FCS_K * FCS_N * 2, 0x00027000);
     const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(wpl), 0, FCS_K * FCS_N * 2, 0x00027000);
-    const int abase = row0 * FCS_ROW_BYTES;
     unsigned aoff[NCH];
     static_for<NCH>([&](auto C) __attribute__((always_inline)) {
         constexpr int c = decltype(C)::value;
@@ -1068,7 +1215,7 @@ __device__ __forceinline__ void fc_split_tile(const u32x4 *__restrict__ a, const
     unsigned char *sdst = lds + prow * FCS_LROW + pq * 16;                   // + c * 16 rows, + buffer
     auto slab_bytes = [&](int s) __attribute__((always_inline)) { const int sg = slab0 + s; return (sg >> 1) * 512 + (sg & 1) * 128; };
     auto load_a = [&](int s, unsigned c_off) __attribute__((always_inline)) {
-        return __builtin_amdgcn_raw_buffer_load_b128(ra, (int)c_off, abase + slab_bytes(s), 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(ra, (int)c_off, slab_bytes(s), 0);
     };
 
     u32x4 stg[2][NCH];
@@ -1088,11 +1235,11 @@ __device__ __forceinline__ void fc_split_tile(const u32x4 *__restrict__ a, const
     });
     __syncthreads();
 
-    f32x16 acc[MTR][2];
-    static_for<MTR>([&](auto T) __attribute__((always_inline)) {
+    f32x16 acc[2 * MTR];                                     // tile 2t + u: row tile t, column tile u
+    static_for<2 * MTR>([&](auto T) __attribute__((always_inline)) {
         constexpr int t = decltype(T)::value;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[t][0][r] = 0.f; acc[t][1][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     });
 
     // weight fragment of (k-step, column tile u): ((kstep*2 + h)*1024 + n) * 16 bytes, n = 256 nb + 64 w + 32 u + m
@@ -1144,9 +1291,9 @@ __device__ __forceinline__ void fc_split_tile(const u32x4 *__restrict__ a, const
                         constexpr int u = decltype(Uu)::value;
                         const half8 xh = as_half8(fh[cur][t]), xl = as_half8(fl[cur][t]);
                         const half8 wh = as_half8(bh[slot][u]), wl = as_half8(bl[slot][u]);
-                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, acc[t][u], 0, 0, 0);
-                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, acc[t][u], 0, 0, 0);
-                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, acc[t][u], 0, 0, 0);
+                        acc[2 * t + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, acc[2 * t + u], 0, 0, 0);
+                        acc[2 * t + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, acc[2 * t + u], 0, 0, 0);
+                        acc[2 * t + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, acc[2 * t + u], 0, 0, 0);
                         // two memory instructions behind every MFMA triple
                         if constexpr (t == 0 && !(ABL & 2)) {    // weights of k-step J + BR - 1
                             bh[fill][u] = load_w(wbh, knext, u);
@@ -1173,30 +1320,24 @@ __device__ __forceinline__ void fc_split_tile(const u32x4 *__restrict__ a, const
         });
     }
 
+    // the two K halves of this tile meet (fc_split_finish); the ticket goes to every wave through LDS, which the
+    // loop's closing barrier has released
+    const int pair = mb * 4 + nb;
+    if (tid == 0)
+        *reinterpret_cast<unsigned *>(lds) = __hip_atomic_fetch_add(fin.ticket + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = *reinterpret_cast<const unsigned *>(lds);
+    fc_split_finish<2 * MTR, 2, 4>(acc, fin, a_inv_scale, sc->inv_swf, ticket, pair,
+                                   (size_t)row0 * FCS_N + (size_t)nb * (32 * MTR * 256), row0, count, max_rows,
+                                   nb * 8 + w * 2, w, lane);
     NNB_SP_STAMP(3) NNB_SP_WALL(6)
-    // epilogue: back to true units with the row's activation scale and the layer's weight scale
-    const float inv_sw = sc->inv_swf;
-    float *obase = part + (size_t)ksp * max_rows * FCS_N + nb * 256 + w * 64 + m;
-    static_for<MTR>([&](auto T) __attribute__((always_inline)) {
-        constexpr int t = decltype(T)::value;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (row < count) {
-                const float k = a_inv_scale[row] * inv_sw;
-                obase[(size_t)row * FCS_N] = acc[t][0][r] * k;
-                obase[(size_t)row * FCS_N + 32] = acc[t][1][r] * k;
-            }
-        }
-    });
 }
 
 template <int BR, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void fc_split_kernel(const u32x4 *__restrict__ a,          // [rows][90][32 chunks]
                                                           const float *__restrict__ a_inv_scale, // [rows]
                                                           const u32x4 *__restrict__ wph, const u32x4 *__restrict__ wpl,
-                                                          const SplitScales *__restrict__ sc,
-                                                          float *__restrict__ part,              // [2][max_rows][1024]
+                                                          const SplitScales *__restrict__ sc, FcFinish fin,
                                                           const int32_t *__restrict__ count_ptr, int n_fixed,
                                                           int max_rows, int shared_chip) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * FCS_LBUF];    // three slab buffers
@@ -1212,10 +1353,10 @@ __global__ __launch_bounds__(256, 1) void fc_split_kernel(const u32x4 *__restric
         mbx = 2;
     }
     const int tiles = (count + 32 * mblocks - 1) / (32 * mblocks);
-    if (tiles <= 1) fc_split_tile<1, BR, ABL>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds, mbx);
-    else if (tiles == 2) fc_split_tile<2, BR, ABL>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds, mbx);
-    else if (tiles == 3) fc_split_tile<3, BR, ABL>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds, mbx);
-    else fc_split_tile<4, BR, ABL>(a, a_inv_scale, wph, wpl, sc, part, count, max_rows, lds, mbx);
+    if (tiles <= 1) fc_split_tile<1, BR, ABL>(a, a_inv_scale, wph, wpl, sc, fin, count, max_rows, lds, mbx);
+    else if (tiles == 2) fc_split_tile<2, BR, ABL>(a, a_inv_scale, wph, wpl, sc, fin, count, max_rows, lds, mbx);
+    else if (tiles == 3) fc_split_tile<3, BR, ABL>(a, a_inv_scale, wph, wpl, sc, fin, count, max_rows, lds, mbx);
+    else fc_split_tile<4, BR, ABL>(a, a_inv_scale, wph, wpl, sc, fin, count, max_rows, lds, mbx);
 }
 
 // Small batches (at most kSplitSmallFc rows: single searches, small tournaments, the last games of a round) are
@@ -1228,7 +1369,7 @@ __global__ __launch_bounds__(256, 1) void fc_split_kernel(const u32x4 *__restric
 template <int DEPTH>
 __global__ __launch_bounds__(64) void fc_split_small_kernel(const u32x4 *__restrict__ a, const float *__restrict__ a_inv_scale,
                                                             const u32x4 *__restrict__ wph, const u32x4 *__restrict__ wpl,
-                                                            const SplitScales *__restrict__ sc, float *__restrict__ part,
+                                                            const SplitScales *__restrict__ sc, FcFinish fin,
                                                             const int32_t *__restrict__ count_ptr, int n_fixed, int max_rows) {
     const int count = batch_count_sp(count_ptr, n_fixed);
     const int bid = blockIdx.x, rt = bid >> 6, ct = (bid >> 1) & 31, ksp = bid & 1;
@@ -1236,12 +1377,15 @@ __global__ __launch_bounds__(64) void fc_split_small_kernel(const u32x4 *__restr
     if (row0 >= count) return;
     const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
     constexpr int KHALF = FCS_K / FCS_SPLIT, NKS = KHALF / 16;           // 360 k-steps of 16
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a), 0, max_rows * FCS_ROW_BYTES, 0x00027000);
+    // the resource starts at this block's first row (64-bit arithmetic), so 32-bit offsets stay inside 32 rows
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char *>(reinterpret_cast<const unsigned char *>(a) + (size_t)row0 * FCS_ROW_BYTES), 0,
+        min(max_rows - row0, 32) * FCS_ROW_BYTES, 0x00027000);
     const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(wph), 0, FCS_K * FCS_N * 2, 0x00027000);
     const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(wpl), 0, FCS_K * FCS_N * 2, 0x00027000);
     // activation fragment of k-step K (global index): 64 k per 256-byte half cell (128 B of hi at +0 / +128, lo 256 B
     // further): byte (K >> 3) * 512 + ((K >> 2) & 1) * 128 + (K & 3) * 32 + h * 16 of the row
-    const int arow = min(row0 + m, max_rows - 1);
+    const int arow = min(row0 + m, max_rows - 1) - row0;
     const int aoff = arow * FCS_ROW_BYTES + h * 16;
     auto a_bytes = [&](int K) __attribute__((always_inline)) { return (K >> 3) * 512 + ((K >> 2) & 1) * 128 + (K & 3) * 32; };
     // weight fragment of k-step K: ((K * 2 + h) * 1024 + n) * 16 bytes, n = 32 ct + m
@@ -1277,12 +1421,43 @@ __global__ __launch_bounds__(64) void fc_split_small_kernel(const u32x4 *__restr
             __builtin_amdgcn_sched_barrier(0);
         });
     }
-    const float inv_sw = sc->inv_swf;
-    float *obase = part + (size_t)ksp * max_rows * FCS_N + ct * 32 + m;
+    // the two K halves of this tile meet (fc_split_finish); neighbouring blocks hold them
+    const int pair = rt * 32 + ct;
+    unsigned ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(fin.ticket + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+    f32x16 tile[1] = {acc};
+    fc_split_finish<1, 1, 1>(tile, fin, a_inv_scale, sc->inv_swf, ticket, pair, (size_t)pair * 1024, row0, count, max_rows, ct, 0, lane);
+}
+
+// The heads from the linear layer's per-tile partial sums (heads_math.h: heads_z_from_q), then log-softmax, tanh and
+// the legal-move mask.  One wave per row.  The search itself does not launch this kernel (the tree step finishes its
+// own leaf from the same sums); it serves nnb_net_forward and the checks.
+__global__ __launch_bounds__(256) void heads_q_kernel(const float *__restrict__ q, const float *__restrict__ hb,
+                                                      const uint8_t *__restrict__ legal, float *__restrict__ logp_out,
+                                                      float *__restrict__ value_out, float *__restrict__ prior_out,
+                                                      const int32_t *__restrict__ count_ptr, int n_fixed) {
+    const int count = batch_count_sp(count_ptr, n_fixed);
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int row = wave; row < count; row += nwaves) {
+        float z[8];
+        heads_z_from_q(q + (size_t)row * 256, hb, lane, z);
+        if (lane == 0) {
+            float lp[7];
+            heads_log_softmax(z, lp);
+            if (logp_out)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < count) obase[(size_t)row * FCS_N] = acc[r] * (a_inv_scale[row] * inv_sw);
+                for (int o = 0; o < 7; ++o) logp_out[(size_t)row * 7 + o] = lp[o];
+            if (value_out) value_out[row] = tanhf(z[7]);
+            if (prior_out && legal) {
+                float pr[7];
+                heads_priors(lp, legal[row], pr);
+#pragma unroll
+                for (int o = 0; o < 7; ++o) prior_out[(size_t)row * 7 + o] = pr[o];
+            }
+        }
     }
 }
 
@@ -1396,23 +1571,32 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
             b.act3_inv, count_ptr, n_max, nullptr, nullptr, nullptr, nullptr);
         break;
     case NET_FC: {
+        const FcFinish fin = {w.fc_b, w.heads_w, b.fcq, b.write_hidden ? b.fc : nullptr, b.fchand, b.fcsync, b.fcsync + b.fc_pairs,
+                              b.sync_err, b.heads_all};
         if (n_max <= kSplitSmallFc) {                            // one wave per 32 rows x 32 columns x K half
             fc_split_small_kernel<12><<<64 * cdiv_sp(n_max, 32), 64, 0, st>>>(
-                a3, b.act3_inv, (const u32x4 *)w.fc_wh, (const u32x4 *)w.fc_wl, w.sp_scales, b.fcpart, count_ptr, n_max,
+                a3, b.act3_inv, (const u32x4 *)w.fc_wh, (const u32x4 *)w.fc_wl, w.sp_scales, fin, count_ptr, n_max,
                 b.max_rows);
             break;
         }
         const int groups = cdiv_sp(cdiv_sp(n_max, 128), 32);       // 32 row blocks per group of 256 blocks
         fc_split_kernel<FCS_BR><<<256 * groups, 256, 0, st>>>(
-            a3, b.act3_inv, (const u32x4 *)w.fc_wh, (const u32x4 *)w.fc_wl, w.sp_scales, b.fcpart, count_ptr, n_max,
+            a3, b.act3_inv, (const u32x4 *)w.fc_wh, (const u32x4 *)w.fc_wl, w.sp_scales, fin, count_ptr, n_max,
             b.max_rows, b.shared_chip);
         break;
     }
-    case NET_HEADS:     // partial sums have the layout of the half-input path: its heads kernel serves both
-        launch_net_stage_f16(st, NET_HEADS, w, b, side, legal, logp_out, value_out, prior_out, count_ptr, n_max);
+    case NET_HEADS: {   // needs the linear layer to have run with heads_all
+        const int blocks = cdiv_sp(n_max, 4);                    // one wave per row
+        heads_q_kernel<<<blocks < 512 ? blocks : 512, 256, 0, st>>>(b.fcq, w.heads_b, legal, logp_out, value_out, prior_out,
+                                                                    count_ptr, n_max);
         break;
+    }
     default: break;
     }
+}
+
+HeadsDev heads_input_split(const NetWeights &w, const NetBuffers &b) {
+    return HeadsDev{b.fcq, nullptr, nullptr, nullptr, w.heads_w, w.heads_b, 0};
 }
 
 void launch_split_to_f32(hipStream_t st, const void *act, const float *inv_scale, int cells, int n, float *out) {

@@ -105,6 +105,7 @@ struct nnb_engine {
     nnb_search_params stream_params = {};
     RoundDev stream_round = {};
     bool separate_convs = false;           // NNB_FLAG_SEPARATE_CONVS of the call in progress
+    bool policy_heads = true;              // the search in progress reads the policy heads (PUCT), not only the value
     bool shared_chip = false;              // two forward passes run side by side on two streams
     int row_bound = 0;                     // > 0: no leaf batch of the rounds being launched holds more rows than this
                                            //      (the occupied slots at the host's last look; they only go down until
@@ -159,6 +160,16 @@ void carve_state(size_t G, size_t cap, int max_sims, int cache_slots, Carver &c,
 size_t carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std::vector<NetWeights> &w) {
     const size_t G = cfg.max_games;
     carve_state(G, 1 + 7 * (size_t)cfg.max_sims, cfg.max_sims, cfg.eval_cache_slots, c, d);
+    // ticket and flag words of the split linear layer's block pairs (they only ever grow; zero at the start)
+    b.fc_pairs = fc_sync_pairs(cfg.max_games);
+    b.fcsync = b.fcsync_b1 = nullptr;
+    if (cfg.net_precision == NNB_NET_F32S) {
+        b.fcsync = c.take<uint32_t>(2 * (size_t)b.fc_pairs);
+        b.fcsync_b1 = c.take<uint32_t>(2 * (size_t)b.fc_pairs);
+    }
+    b.sync_err = d.counters ? d.counters + kSyncErr : nullptr;
+    b.fcq = b.fcq_b1 = b.fchand = b.fchand_b1 = nullptr;
+    b.heads_all = 1; b.write_hidden = 0;
     c.take<unsigned char>(kAlign);
     const size_t state_bytes = c.off;
     if (cfg.net_precision == NNB_NET_F32) {
@@ -175,13 +186,17 @@ size_t carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std:
     } else if (cfg.net_precision == NNB_NET_F32S) {      // hi + lo halves: 4 bytes per value, plus a scale per board
         const bool two = true;
         b.act1 = b.act1_b1 = nullptr;
-        b.fc = b.fc_b1 = nullptr;
+        b.fc = c.take<float>(G * 1024);                 // hidden activations, written for nnb_debug_activations only
+        b.fc_b1 = nullptr;
         b.act2 = c.take<float>(G * 72 * 128);
         b.act3 = c.take<float>(G * 90 * 128);
         b.act2_inv = c.take<float>(G);
         b.act3_inv = c.take<float>(G);
-        b.fcpart = c.take<float>(2 * G * 1024);
-        b.fcpart_b1 = c.take<float>(2 * G * 1024);
+        b.fcpart = b.fcpart_b1 = nullptr;
+        b.fchand = c.take<float>((G + 128) * 1024);     // a row block may reach 127 rows past the last row
+        b.fchand_b1 = c.take<float>((G + 128) * 1024);
+        b.fcq = c.take<float>(G * 256);
+        b.fcq_b1 = c.take<float>(G * 256);
         b.act2_b1 = two ? c.take<float>(G * 72 * 128) : nullptr;
         b.act3_b1 = two ? c.take<float>(G * 90 * 128) : nullptr;
         b.act2_inv_b1 = two ? c.take<float>(G) : nullptr;
@@ -339,6 +354,7 @@ NetBuffers batch_buffers(const nnb_engine *e, int batch) {
     b.shared_chip = e->shared_chip ? 1 : 0;
     if (batch == 1) {
         b.fc = b.fc_b1; b.fcpart = b.fcpart_b1;
+        b.fcq = b.fcq_b1; b.fchand = b.fchand_b1; b.fcsync = b.fcsync_b1;
         b.act1 = b.act1_b1; b.act2 = b.act2_b1; b.act3 = b.act3_b1;
         b.act2_inv = b.act2_inv_b1; b.act3_inv = b.act3_inv_b1;
     }
@@ -347,6 +363,7 @@ NetBuffers batch_buffers(const nnb_engine *e, int batch) {
 
 HeadsDev heads_input(const nnb_engine *e, int weight_set, int batch) {
     const NetBuffers b = batch_buffers(e, batch);
+    if (e->cfg.net_precision == NNB_NET_F32S) return heads_input_split(e->weights[weight_set], b);
     return e->cfg.net_precision == NNB_NET_F32 ? heads_input_f32(e->weights[weight_set], b)
                                                : heads_input_f16(e->weights[weight_set], b);
 }
@@ -358,7 +375,9 @@ void forward_leaves(nnb_engine *e, hipStream_t st, int weight_set, int batch, in
     const int32_t *count_ptr = e->dev.leaf_count + 2 * parity + batch;
     const NetWeights &w = e->weights[weight_set];
     const EngineDev &d = e->dev;
-    const NetBuffers nb = batch_buffers(e, batch);
+    NetBuffers nb = batch_buffers(e, batch);
+    // the reference rule ignores priors: when the tree step finishes the heads itself, the value head is all it reads
+    nb.heads_all = (with_heads || e->policy_heads) ? 1 : 0;
     const size_t o = (size_t)batch * d.max_games;
     const bool fused_in = e->cfg.net_precision != NNB_NET_F32;     // conv0 is part of the conv2 launch there
     if (!fused_in) { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, nb, d.leaf_side + 2 * o, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
@@ -385,6 +404,7 @@ struct StepPlan {
 
 StepPlan make_step_plan(nnb_engine *e, const nnb_search_params &p, const SearchDev &sd) {
     StepPlan plan = {};
+    e->policy_heads = p.mode == NNB_MODE_AZ;
     plan.nbatch = sd.wset[0] == sd.wset[1] ? 1 : 2;
     plan.heads.fused = p.evaluator == NNB_EVAL_NET && !(p.flags & NNB_FLAG_SEPARATE_HEADS);
     if (plan.heads.fused)
@@ -461,8 +481,12 @@ int collect_stats(nnb_engine *e, hipStream_t st, nnb_round_stats *out, long long
     HIP_TRY(hipMemsetAsync(e->dev.stats64, 0, 8 * sizeof(unsigned long long), st));
     launch_stats_reduce(st, e->dev);
     HIP_TRY(hipMemcpyAsync(e->host_stats, e->dev.stats64, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(e->host_counters + 8, e->dev.counters + kSyncErr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     prof_drain(e);
+    if (e->host_counters[8])
+        return fail(NNB_ERR_HIP, "%d block(s) of the linear layer waited in vain for their partner's partial sums: the "
+                    "evaluations of this call are invalid", e->host_counters[8]);
     if (out) {
         out->games = n;
         out->depth_sum = (int64_t)e->host_stats[0];
@@ -586,10 +610,14 @@ int run_free_rounds(nnb_engine *e, hipStream_t st, const nnb_search_params &para
     SearchDev sd = lockstep_search_dev(params);
     const int slots = e->dev.n_games;
     StepPlan plan = make_step_plan(e, params, sd);
-    constexpr int kChunk = 64;
+#ifndef NNB_LOOK_ROUNDS
+#define NNB_LOOK_ROUNDS 64
+#endif
+    constexpr int kChunk = NNB_LOOK_ROUNDS;             // lock-step rounds between two looks of the host at the counters
     e->prof_stride = kChunk / kProfSamples + 1;
     long long steps = 0;
-    HIP_TRY(hipMemcpyAsync(e->host_counters, e->dev.counters + kLive, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    static_assert(kFinished == kLive + 1 && kSyncErr == kLive + 2, "the host reads the three counters with one copy");
+    HIP_TRY(hipMemcpyAsync(e->host_counters, e->dev.counters + kLive, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     int live = e->host_counters[0];
     long long finished = (unsigned)e->host_counters[1];
@@ -599,7 +627,7 @@ int run_free_rounds(nnb_engine *e, hipStream_t st, const nnb_search_params &para
     auto look = [&]() -> hipError_t {
         hipError_t err = hipGetLastError();
         if (err != hipSuccess) return err;
-        err = hipMemcpyAsync(e->host_counters, e->dev.counters + kLive, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        err = hipMemcpyAsync(e->host_counters, e->dev.counters + kLive, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
         if (err != hipSuccess) return err;
         err = hipStreamSynchronize(st);
         if (err != hipSuccess) return err;
@@ -642,9 +670,10 @@ int run_free_rounds(nnb_engine *e, hipStream_t st, const nnb_search_params &para
             (void)hipEventRecord(e->join_event, e->side_stream);
             (void)hipStreamWaitEvent(st, e->join_event, 0);
             HIP_TRY(look());
+            if (e->host_counters[2]) break;
         }
     }
-    while (!halves && go_on()) {
+    while (!halves && go_on() && !e->host_counters[2]) {
         for (int k = 0; k < kChunk; ++k, ++steps) {
             if (make_noise) launch_turnover(st, e->dev, sd, round, make_noise);
             lockstep_step(e, st, params, sd, plan, (int)((step0 + steps) & 1), true, make_noise ? nullptr : &round);
@@ -653,6 +682,9 @@ int run_free_rounds(nnb_engine *e, hipStream_t st, const nnb_search_params &para
     }
     e->shared_chip = false;
     e->row_bound = 0;
+    if (e->host_counters[2])
+        return fail(NNB_ERR_HIP, "%d block(s) of the linear layer waited in vain for their partner's partial sums: the "
+                    "evaluations of this call are invalid", e->host_counters[2]);
     *steps_out = steps; *live_out = live; *finished_out = finished; *chains_out = halves ? 2 : 1;
     return NNB_OK;
 }
@@ -815,6 +847,8 @@ int nnb_net_forward(nnb_engine *e, int weight_set, void *stream, int32_t n, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     const NetWeights &w = e->weights[weight_set];
     const u64 *side = reinterpret_cast<const u64 *>(side_boards);
+    e->buf.heads_all = 1;
+    e->buf.write_hidden = 1;                             // for nnb_debug_activations
     { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, e->buf, side, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
     if (e->cfg.net_precision == NNB_NET_F32S) {         // one launch; the middle activations are copied out for nnb_debug_activations
         ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV_PAIR_MID, w, e->buf, side, nullptr, nullptr, nullptr, nullptr, nullptr, n);
@@ -824,6 +858,7 @@ int nnb_net_forward(nnb_engine *e, int weight_set, void *stream, int32_t n, cons
     }
     { ProfScope ps(e, 4, st); net_stage(e, st, NET_FC, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
     { ProfScope ps(e, 5, st); net_stage(e, st, NET_HEADS, w, e->buf, nullptr, legal_masks, log_policy_out, value_out, priors_out, nullptr, n); }
+    e->buf.write_hidden = 0;
     HIP_TRY(hipGetLastError());
     return NNB_OK;
 }
@@ -853,7 +888,7 @@ int nnb_debug_activations(nnb_engine *e, int weight_set, void *stream, int layer
     if (layer == 4) {
         const size_t total = (size_t)n * 1024;
         const unsigned blocks = (unsigned)((total + 255) / 256);
-        if (prec == NNB_NET_F32) debug_act_kernel<<<blocks, 256, 0, st>>>(0, b.fc, nullptr, nullptr, total, out);
+        if (prec == NNB_NET_F32 || prec == NNB_NET_F32S) debug_act_kernel<<<blocks, 256, 0, st>>>(0, b.fc, nullptr, nullptr, total, out);
         else debug_act_kernel<<<blocks, 256, 0, st>>>(2, b.fcpart, b.fcpart + (size_t)b.max_rows * 1024,
                                                       e->weights[weight_set].fc_b, total, out);
     } else {
@@ -1015,6 +1050,13 @@ int nnb_selfplay_stream(nnb_engine *e, void *stream, const nnb_search_params *pa
     int rc = run_free_rounds(e, st, p, e->stream_round, make_noise, e->stream_steps, max_steps,
                              e->stream_finished + min_finished, &steps, &live, &finished, &chains);
     if (rc) { e->stream_on = false; return rc; }
+    if (finished - e->stream_finished > e->stream_round.ring_len - e->stream_slots) {
+        // more games finished inside this call than the ring holds beside the games in flight (very short searches,
+        // or start positions that are mostly finished): records it was about to report have been overwritten
+        e->stream_on = false;
+        return fail(NNB_ERR_STATE, "%lld games finished in one call but the record ring holds %d: records were overwritten; "
+                    "use a longer ring or a smaller min_finished", finished - e->stream_finished, e->stream_round.ring_len);
+    }
     e->stream_steps += steps;
     nnb_round_stats total;
     rc = collect_stats(e, st, &total, steps, (steps + p.sims) / (p.sims + 1), 0, chains);

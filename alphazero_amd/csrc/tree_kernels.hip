@@ -447,7 +447,10 @@ constexpr int kStepGames = 16;                    // games (wavefronts) per bloc
 // but at most this many per step: a game deep in a won position would otherwise run its whole
 // budget inside one launch while the other 15 waves of its block (and the batch) wait.  The
 // order of a game's simulations is unchanged, so results are too; S+1 steps still suffice.
-constexpr int kTerminalSimsPerStep = 6;
+#ifndef NNB_TERMINAL_SIMS_PER_STEP
+#define NNB_TERMINAL_SIMS_PER_STEP 6
+#endif
+constexpr int kTerminalSimsPerStep = NNB_TERMINAL_SIMS_PER_STEP;
 
 __device__ void readout_game(const EngineDev &e, const SearchDev &p, int g, int32_t *__restrict__ visits_out,
                              int8_t *__restrict__ action_out, double *__restrict__ root_value_out,
@@ -470,7 +473,10 @@ __device__ void readout_game(const EngineDev &e, const SearchDev &p, int g, int3
 // SPAN: the launch covers games [span.first, span.end) only and files its leaves in batch span.batch
 // (-1: batch by root mover's weight set, as above).  Two launches over the two halves of the slots, each
 // with a batch and a stream of its own, let one half's tree step run under the other half's forward pass.
-template <bool AZ, bool HEADS, bool TURNOVER, bool CACHE>
+// HEADS = 1: from the linear layer's output (or its two split-K partial sums), head rows in LDS; HEADS = 2: from the
+// per-column-tile partial sums of the heads that the split linear layer's last step leaves (128 bytes per leaf under
+// the reference rule, 1 KB under PUCT; nothing staged in LDS).
+template <bool AZ, int HEADS, bool TURNOVER, bool CACHE>
 __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e, SearchDev p, int parity, HeadsPair hp,
                                                                     RoundDev round, GameSpan span) {
     __shared__ int s_want[kStepGames];       // 0 = no leaf, 1 + batch otherwise
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
     constexpr int HROWS = AZ ? 8 : 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int g = span.first + blockIdx.x * kStepGames + wv;
-    if constexpr (HEADS) {
+    if constexpr (HEADS == 1) {
         const int nb = p.wset[0] != p.wset[1] ? 2 : 1;
         for (int i = threadIdx.x; i < nb * HROWS * 256; i += kStepGames * 64) {
             const int b = i / (HROWS * 256), r = i % (HROWS * 256);
@@ -532,7 +538,22 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
         int mypath = e.path[g * kPathSlots + lane];
         double v;
         float pr = 0.0f;
-        if constexpr (HEADS) {
+        if constexpr (HEADS == 2) {
+            const int b = pend >= e.max_games ? 1 : 0;
+            const HeadsDev &hd = hp.h[b];
+            const float *qrow = hd.q + (size_t)(pend - b * e.max_games) * 256;
+            if constexpr (AZ) {
+                float z[8], lp[7], pri[7];
+                heads_z_from_q(qrow, hd.hb, lane, z);
+                heads_log_softmax(z, lp);
+                heads_priors(lp, legal_in[pend], pri);
+#pragma unroll
+                for (int o = 0; o < 7; ++o) pr = lane == o ? pri[o] : pr;
+                v = (double)tanhf(z[7]);
+            } else {
+                v = (double)tanhf(heads_value_from_q(qrow, hd.hb, lane));   // value.item(), agent_code.py:213
+            }
+        } else if constexpr (HEADS == 1) {
             const int b = pend >= e.max_games ? 1 : 0;
             const HeadsDev &hd = hp.h[b];
             float4 xv[4];
@@ -1116,7 +1137,7 @@ void launch_tree_init(hipStream_t st, const EngineDev &e, const SearchDev &p, in
     tree_init_kernel<<<cdiv(e.n_games, 256), 256, 0, st>>>(e, p, make_noise, selfplay);
 }
 
-template <bool AZ, bool HEADS>
+template <bool AZ, int HEADS>
 static void launch_tree_step_t(hipStream_t st, const EngineDev &e, const SearchDev &p, int parity, const HeadsPair &heads,
                                const RoundDev *turnover, size_t lds, const GameSpan &span) {
     const int blocks = cdiv(span.end - span.first, kStepGames), threads = kStepGames * 64;
@@ -1137,13 +1158,16 @@ void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, in
                       const RoundDev *turnover, const GameSpan *span_or_null) {
     const bool az = p.mode == NNB_MODE_AZ;
     const GameSpan span = span_or_null ? *span_or_null : GameSpan{0, e.n_games, -1};
-    if (heads.fused) {
+    if (heads.fused && heads.h[0].q) {
+        if (az) launch_tree_step_t<true, 2>(st, e, p, parity, heads, turnover, 0, span);
+        else launch_tree_step_t<false, 2>(st, e, p, parity, heads, turnover, 0, span);
+    } else if (heads.fused) {
         const size_t lds = (size_t)(p.wset[0] != p.wset[1] ? 2 : 1) * (az ? 8 : 1) * 4096;
-        if (az) launch_tree_step_t<true, true>(st, e, p, parity, heads, turnover, lds, span);
-        else launch_tree_step_t<false, true>(st, e, p, parity, heads, turnover, lds, span);
+        if (az) launch_tree_step_t<true, 1>(st, e, p, parity, heads, turnover, lds, span);
+        else launch_tree_step_t<false, 1>(st, e, p, parity, heads, turnover, lds, span);
     } else {
-        if (az) launch_tree_step_t<true, false>(st, e, p, parity, heads, turnover, 0, span);
-        else launch_tree_step_t<false, false>(st, e, p, parity, heads, turnover, 0, span);
+        if (az) launch_tree_step_t<true, 0>(st, e, p, parity, heads, turnover, 0, span);
+        else launch_tree_step_t<false, 0>(st, e, p, parity, heads, turnover, 0, span);
     }
 }
 
@@ -1157,10 +1181,10 @@ hipError_t prepare_tree_fused(size_t lds_bytes) {
 
 // The PUCT step kernel of a two-network arena stages 2 x 8 head rows = 64 KB of dynamic LDS.
 hipError_t prepare_tree_step() {
-    const void *k[4] = {reinterpret_cast<const void *>(tree_step_kernel<true, true, false, false>),
-                        reinterpret_cast<const void *>(tree_step_kernel<true, true, true, false>),
-                        reinterpret_cast<const void *>(tree_step_kernel<true, true, false, true>),
-                        reinterpret_cast<const void *>(tree_step_kernel<true, true, true, true>)};
+    const void *k[4] = {reinterpret_cast<const void *>(tree_step_kernel<true, 1, false, false>),
+                        reinterpret_cast<const void *>(tree_step_kernel<true, 1, true, false>),
+                        reinterpret_cast<const void *>(tree_step_kernel<true, 1, false, true>),
+                        reinterpret_cast<const void *>(tree_step_kernel<true, 1, true, true>)};
     for (const void *f : k) {
         hipError_t err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4096);
         if (err != hipSuccess) return err;

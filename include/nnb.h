@@ -291,11 +291,13 @@ int nnb_search(nnb_engine *engine, void *stream, const nnb_search_params *params
  * search state that nnb_search keeps in the engine's workspace lives in a fixed array inside the
  * library instead (512 KB, one copy per GPU, held until the process ends), so there is no engine, no
  * workspace and no call to hipMalloc / hipFree or to any allocating routine; the first call on a
- * device lays that array out and fills its log table.  Limits: n <= NNB_STATIC_MAX_ROOTS roots,
+ * device lays that array out and fills its log table, WAITS for that set-up on `stream` (so later
+ * calls on any stream find it done) and is refused with NNB_ERR_STATE while `stream` is capturing:
+ * make one eager call per device before capturing.  Limits: n <= NNB_STATIC_MAX_ROOTS roots,
  * params->sims <= NNB_STATIC_MAX_SIMS, a fixed evaluator (CONST, HASH_Q8, HASH_F32 or ROLLOUT - the
  * network's activations do not fit), params->flags == 0; anything beyond is refused with NNB_ERR_ARG.
  * Arguments and results are those of nnb_search, bit for bit; there are no statistics, and the call is
- * ASYNCHRONOUS on `stream` on the current device.  All calls on one GPU share that GPU's array: calls
+ * ASYNCHRONOUS on `stream` on the current device (the first call on a device excepted).  All calls on one GPU share that GPU's array: calls
  * that overlap in time on one GPU (two streams, two threads) race and must be serialised by the caller. */
 #define NNB_STATIC_MAX_ROOTS 256
 #define NNB_STATIC_MAX_SIMS 800
@@ -336,6 +338,10 @@ int nnb_selfplay_round(nnb_engine *engine, void *stream, const nnb_search_params
  * min_finished <= ring_len - 2 * max_games (a call's records must fit the ring beside the games in flight); a record is
  * reused ring_len games later, so the caller copies finished records out between calls (a game that lasts
  * while ring_len - max_games later games are seated would be overwritten; no legal game does at 4 x).
+ * The host looks at the device's counters every 64 lock-step rounds only, so a call can overshoot min_finished;
+ * if more than ring_len - max_games games finish inside one call (searches of a handful of simulations, or
+ * start positions that are mostly finished) records it was about to report have been overwritten: the call
+ * then fails with NNB_ERR_STATE and the stream is ended.
  * stats_out counts the work of this call only.  Any other call that searches or runs the network on this
  * engine ends the stream (the next call needs restart != 0).  nnb_load_weights between two calls does not:
  * the games in flight carry on and every later leaf is judged by the new weights, as when the training loop
@@ -348,9 +354,14 @@ int nnb_selfplay_stream(nnb_engine *engine, void *stream, const nnb_search_param
                         const int8_t *start_players, int32_t n_starts, nnb_trajectory *record_ring,
                         int32_t *finished_ring, int32_t ring_len, nnb_round_stats *stats_out);
 
-/* Records -> per-ply training samples on the device, what AlphaZeroAgent.self_play keeps per move
+/* Records -> per-ply training samples on the device: the per-move targets AlphaZeroAgent.self_play INTENDS
  * (agent_code.py:254-267: state, MCTS visit distribution, value target) in the form ConnectFourDataset
- * stacks (data_module.py:13-27).  For ply k < length of record i, sample s = ply_offsets[i] + k:
+ * stacks (data_module.py:13-27).  Not literal parity with that (dead) method, and no reference fixture covers
+ * it: the reference stores the raw board (state.copy(), agent_code.py:256), not planes, and flips its player
+ * variable with `player = -player` (agent_code.py:266), so the second mover's target is -1 in every decided
+ * game.  What is built here is the mover-relative target below; the only pin is this repository's own host
+ * loop (alphazero_amd.selfplay.self_play_samples), which the kernel equals bit for bit.
+ * For ply k < length of record i, sample s = ply_offsets[i] + k:
  *   planes_out[s]  float32 [2,6,7]: plane 0 the mover's stones, plane 1 the rival's, row 0 = top
  *                  (preprocess, agent_code.py:76-89), the position BEFORE the move;
  *   probs_out[s]   float32 [7]: root visit counts / their sum (agent_code.py:226-232; zeros if no visits);

@@ -108,15 +108,16 @@ def test_stream_argument_checks(gpu):
 
 def test_stream_of_finished_start_positions_ends(gpu):
     """Start positions that are all finished: every game is recorded as it is seated, no slot ever holds a game,
-    and the call must come back (with what it recorded) instead of seating for ever."""
+    and the call must come back instead of seating for ever - with an error, because the slots recorded far more
+    games than the ring holds before they gave up."""
     from alphazero_amd.engine import Engine
     eng = Engine(max_games=16, max_sims=8)
     try:
         p = eng.params(8, 1.4, evaluator="hash_q8", lockstep=True)
         won = np.array([[0b1111, 0b1110000000]], dtype=np.uint64)          # colour 1 has four in the first column
-        r, st = eng.selfplay_stream(96, p, restart=True, start_boards=won, start_players=np.array([2], dtype=np.int8))
-        assert st["games"] >= 96 and st["sims"] == 0                       # recorded, never played; every slot gave up
-        with pytest.raises(Exception, match="stopped"):                     # nothing is seated any more
+        with pytest.raises(Exception, match="overwritten"):                 # recorded, never played; every slot gave up
+            eng.selfplay_stream(96, p, restart=True, start_boards=won, start_players=np.array([2], dtype=np.int8))
+        with pytest.raises(Exception, match="restart"):                     # nothing is seated any more
             eng.selfplay_stream(1)
     finally:
         eng.close()

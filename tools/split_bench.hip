@@ -42,7 +42,14 @@ int main(int argc, char **argv) {
     float *bias, *inv, *inv_o, *part; SplitScales *sc; unsigned long long *side;
     CK(hipMalloc((void **)&bias, 1024 * 4)); CK(hipMemset(bias, 0, 1024 * 4));
     CK(hipMalloc((void **)&inv, (size_t)n * 4)); CK(hipMalloc((void **)&inv_o, (size_t)n * 4));
-    CK(hipMalloc((void **)&part, (size_t)2 * n * 1024 * 4));
+    CK(hipMalloc((void **)&part, (size_t)(n + 128) * 1024 * 4));
+    float *fcq, *headw; unsigned *fsync; int32_t *ferr;
+    CK(hipMalloc((void **)&fcq, (size_t)n * 256 * 4)); CK(hipMalloc((void **)&headw, 8 * 1024 * 4)); CK(hipMemset(headw, 0, 8 * 1024 * 4));
+    const int npairs = fc_sync_pairs(n);
+    CK(hipMalloc((void **)&fsync, (size_t)2 * npairs * 4)); CK(hipMemset(fsync, 0, (size_t)2 * npairs * 4));
+    CK(hipMalloc((void **)&ferr, 4)); CK(hipMemset(ferr, 0, 4));
+    const int heads_all = argc > 2 ? atoi(argv[2]) : 0;
+    const FcFinish fin = {bias, headw, fcq, nullptr, part, fsync, fsync + npairs, ferr, heads_all};
     std::vector<float> ones(n, 1.0f / 16384.f); CK(hipMemcpy(inv, ones.data(), n * 4, hipMemcpyHostToDevice));
     SplitScales hs = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f / 16384.f, 1.f, 1.f / 16384.f, 1.f, 1.f / 16384.f};
     CK(hipMalloc((void **)&sc, sizeof hs)); CK(hipMemcpy(sc, &hs, sizeof hs, hipMemcpyHostToDevice));
@@ -79,6 +86,14 @@ int main(int argc, char **argv) {
                us, (double)n * 2 * 128 * (72 + 90) * 2048 / (us * 1e-6) / 1e12, h[1] - h[0], h[2] - h[1], h[4] - h[2], h[7] - h[4], h[3] - h[7], h[3] - h[0],
                (double)(h[3] - h[0]) / (double)(h[6] - h[5]) * 100.0);
     }
+    {   // the one-board-per-block form (two blocks per CU, 29 % more MFMAs) on the full batch: does a second resident block
+        // fill the matrix pipe's idle phases, and what does the clock do then?
+        float t = time_it([&] {
+            conv_pair_split_small_kernel<4, 8, false><<<n, 256, conv_pair_small_lds_bytes(), 0>>>(
+                side, w0h, w0l, bias, w2h, w2l, bias, w2h, w2l, bias, sc, nullptr, nullptr, act3, inv_o, nullptr, n);
+        });
+        printf("both convs, one board per block, 2 blocks per CU: %8.1f us  (2304 MFMAs per wave and board against 1792)\n", t);
+    }
     {   // two half batches on two streams (conv 7x8 + conv 8x9 each) against the same work on one stream
         hipStream_t s1, s2; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
         const int nh = n / 2;
@@ -112,7 +127,7 @@ int main(int argc, char **argv) {
         constexpr int BR = decltype(BRc)::value, ABL = decltype(ABLc)::value;
         float t = time_it([&] {
             int groups = cdiv_sp(cdiv_sp(rows, 128), 32);
-            fc_split_kernel<BR, ABL><<<256 * groups, 256, 0, 0>>>(a3, inv, wfh, wfl, sc, part, nullptr, rows, n, 0);
+            fc_split_kernel<BR, ABL><<<256 * groups, 256, 0, 0>>>(a3, inv, wfh, wfl, sc, fin, nullptr, rows, n, 0);
         });
         unsigned long long h[8]; CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sp_clk), sizeof h));
         printf("linear 11520->1024, %4d rows, ring %d, ablate %2d: %8.1f us  %7.1f TFLOP/s  block %llu cycles, clock %.0f MHz\n", rows, BR, ABL, t,
@@ -126,5 +141,7 @@ int main(int argc, char **argv) {
     fc_run(std::integral_constant<int, 8>{}, std::integral_constant<int, 8>{}, n);
     fc_run(std::integral_constant<int, 8>{}, std::integral_constant<int, 15>{}, n);
     fc_run(std::integral_constant<int, 6>{}, I0{}, n / 2);
+    fc_run(std::integral_constant<int, 6>{}, I0{}, n);
+    { int herr = 0; CK(hipMemcpy(&herr, ferr, 4, hipMemcpyDeviceToHost)); printf("linear layer: %d waits between partner blocks ran out\n", herr); }
     return 0;
 }
