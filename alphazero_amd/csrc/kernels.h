@@ -89,6 +89,8 @@ struct NetBuffers {            // activations, channels-last float32
     int fc_pairs;              // ticket words per batch (the flag words follow them)
     int heads_all;             // 1: the linear layer's last step produces all 8 heads, 0: the value head only
     int write_hidden;          // 1: it also writes the hidden activations to `fc`
+    unsigned long long *clk;   // non-null while profiling: [0..3] the convolution launch's, [4..7] the linear layer's
+                               // (shader cycles, 100 MHz wall clock) at the start and at the end of block 0
     int max_rows;              // G
     int shared_chip;           // 1: another forward pass runs beside this one on a second stream (two chains of a
                                //    self-play round, the two networks of an arena): with 1025..2048 rows the linear

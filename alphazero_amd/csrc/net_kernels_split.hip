@@ -165,11 +165,13 @@ __device__ __forceinline__ void conv_split_row(f32x16 (&acc)[NACC], u32x4 (&bh)[
         const int step0 = (KH * 4 + kw) * 8;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
+#ifndef NNB_ABL_NO_CONV_WEIGHT_LOADS                              // (timing experiments only: tools/split_bench.hip)
             {                                                    // weights BRING-1 k-steps ahead: buffer loads with a scalar
                 const int nxt = step0 + ks + BRING - 1;            // offset per k-step (no 64-bit address arithmetic per lane);
                 bh[(ks + BRING - 1) & (BRING - 1)] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, nxt * 4096, 0);   // past the last
                 bl[(ks + BRING - 1) & (BRING - 1)] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, nxt * 4096, 0);   // k-step: zeros, unused
             }
+#endif
             const half8 wh = as_half8(bh[ks & (BRING - 1)]), wl = as_half8(bl[ks & (BRING - 1)]);
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
@@ -513,8 +515,12 @@ __global__ __launch_bounds__(256, 1) void conv_pair_split_kernel(const u64 *__re
                                                                  const SplitScales *__restrict__ sc,
                                                                  u32x4 *__restrict__ mid, float *__restrict__ mid_inv_scale,
                                                                  u32x4 *__restrict__ out, float *__restrict__ out_inv_scale,
-                                                                 const int32_t *__restrict__ count_ptr, int n_fixed) {
+                                                                 const int32_t *__restrict__ count_ptr, int n_fixed,
+                                                                 unsigned long long *__restrict__ clk) {
     constexpr int PB = SP_PB, LEAD = 2;
+    // clk != null (profiling): block 0 stamps the shader-cycle counter and the 100 MHz wall clock at its start and
+    // end, from which the host reads the shader clock this kernel ran at
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter(); clk[1] = wall_clock64(); }
     // first layer: 7x8 -> 8x9; second: 8x9 -> 9x10
     constexpr int IH1 = 7, IW1 = 8, IP1 = IH1 * IW1, W21 = IW1 + 2, BS1 = conv_board_stride(IH1, IW1), NPOS1 = LEAD + NB * BS1 + 2;
     constexpr int IH2 = 8, IW2 = 9, IP2 = IH2 * IW2, W22 = IW2 + 2, BS2 = conv_board_stride(IH2, IW2), NPOS2 = LEAD + NB * BS2 + 2;
@@ -761,6 +767,7 @@ __global__ __launch_bounds__(256, 1) void conv_pair_split_kernel(const u64 *__re
     });
     if (tid < nb_valid) out_inv_scale[b0i + tid] = my_inv;
     NNB_SP_STAMP(3) NNB_SP_WALL(6)
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[2] = __builtin_readcyclecounter(); clk[3] = wall_clock64(); }
 }
 
 // ---------------------------------------------------------------------------
@@ -1339,8 +1346,9 @@ __global__ __launch_bounds__(256, 1) void fc_split_kernel(const u32x4 *__restric
                                                           const u32x4 *__restrict__ wph, const u32x4 *__restrict__ wpl,
                                                           const SplitScales *__restrict__ sc, FcFinish fin,
                                                           const int32_t *__restrict__ count_ptr, int n_fixed,
-                                                          int max_rows, int shared_chip) {
+                                                          int max_rows, int shared_chip, unsigned long long *__restrict__ clk) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * FCS_LBUF];    // three slab buffers
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter(); clk[1] = wall_clock64(); }
     const int count = batch_count_sp(count_ptr, n_fixed);
     int mblocks = gridDim.x >> 3;                            // row blocks the grid provides (8 column/K blocks each)
     int mbx = 4;
@@ -1357,6 +1365,7 @@ __global__ __launch_bounds__(256, 1) void fc_split_kernel(const u32x4 *__restric
     else if (tiles == 2) fc_split_tile<2, BR, ABL>(a, a_inv_scale, wph, wpl, sc, fin, count, max_rows, lds, mbx);
     else if (tiles == 3) fc_split_tile<3, BR, ABL>(a, a_inv_scale, wph, wpl, sc, fin, count, max_rows, lds, mbx);
     else fc_split_tile<4, BR, ABL>(a, a_inv_scale, wph, wpl, sc, fin, count, max_rows, lds, mbx);
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[2] = __builtin_readcyclecounter(); clk[3] = wall_clock64(); }
 }
 
 // Small batches (at most kSplitSmallFc rows: single searches, small tournaments, the last games of a round) are
@@ -1550,7 +1559,7 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
         conv_pair_split_kernel<CS_NB, 4, 8, false><<<cdiv_sp(n_max, CS_NB), 256, CPS_SPLIT_LDS, st>>>(
             side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
             (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b, w.sp_scales,
-            nullptr, nullptr, a3, b.act3_inv, count_ptr, n_max);
+            nullptr, nullptr, a3, b.act3_inv, count_ptr, n_max, b.clk);
         break;
     case NET_CONV_PAIR_MID:     // the same, and the middle activations are copied out as the two-launch form leaves them
         if (n_max <= kSplitSmallConv) {
@@ -1563,7 +1572,7 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
         conv_pair_split_kernel<CS_NB, 4, 8, true><<<cdiv_sp(n_max, CS_NB), 256, CPS_SPLIT_LDS, st>>>(
             side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
             (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b, w.sp_scales,
-            a2, b.act2_inv, a3, b.act3_inv, count_ptr, n_max);
+            a2, b.act2_inv, a3, b.act3_inv, count_ptr, n_max, b.clk);
         break;
     case NET_CONV4:
         conv_rows_split_kernel<8, 9, CS_NB, 4, 8, false><<<cdiv_sp(n_max, CS_NB), 256, C4S_SPLIT_LDS, st>>>(
@@ -1582,7 +1591,7 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
         const int groups = cdiv_sp(cdiv_sp(n_max, 128), 32);       // 32 row blocks per group of 256 blocks
         fc_split_kernel<FCS_BR><<<256 * groups, 256, 0, st>>>(
             a3, b.act3_inv, (const u32x4 *)w.fc_wh, (const u32x4 *)w.fc_wl, w.sp_scales, fin, count_ptr, n_max,
-            b.max_rows, b.shared_chip);
+            b.max_rows, b.shared_chip, b.clk ? b.clk + 4 : nullptr);
         break;
     }
     case NET_HEADS: {   // needs the linear layer to have run with heads_all

@@ -168,6 +168,7 @@ size_t carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std:
         b.fcsync_b1 = c.take<uint32_t>(2 * (size_t)b.fc_pairs);
     }
     b.sync_err = d.counters ? d.counters + kSyncErr : nullptr;
+    b.clk = c.take<unsigned long long>(8);              // profiling stamps; kernels get the pointer only while profiling is on
     b.fcq = b.fcq_b1 = b.fchand = b.fchand_b1 = nullptr;
     b.heads_all = 1; b.write_hidden = 0;
     c.take<unsigned char>(kAlign);
@@ -352,6 +353,7 @@ void net_stage(nnb_engine *e, hipStream_t st, int stage, const NetWeights &w, co
 NetBuffers batch_buffers(const nnb_engine *e, int batch) {
     NetBuffers b = e->buf;
     b.shared_chip = e->shared_chip ? 1 : 0;
+    if (!e->prof_on || batch == 1) b.clk = nullptr;      // one writer: launches of the two batches overlap in time
     if (batch == 1) {
         b.fc = b.fc_b1; b.fcpart = b.fcpart_b1;
         b.fcq = b.fcq_b1; b.fchand = b.fchand_b1; b.fcsync = b.fcsync_b1;
@@ -847,18 +849,18 @@ int nnb_net_forward(nnb_engine *e, int weight_set, void *stream, int32_t n, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     const NetWeights &w = e->weights[weight_set];
     const u64 *side = reinterpret_cast<const u64 *>(side_boards);
-    e->buf.heads_all = 1;
-    e->buf.write_hidden = 1;                             // for nnb_debug_activations
-    { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, e->buf, side, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+    NetBuffers nb = batch_buffers(e, 0);
+    nb.heads_all = 1;
+    nb.write_hidden = 1;                                 // for nnb_debug_activations
+    { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, nb, side, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
     if (e->cfg.net_precision == NNB_NET_F32S) {         // one launch; the middle activations are copied out for nnb_debug_activations
-        ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV_PAIR_MID, w, e->buf, side, nullptr, nullptr, nullptr, nullptr, nullptr, n);
+        ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV_PAIR_MID, w, nb, side, nullptr, nullptr, nullptr, nullptr, nullptr, n);
     } else {
-        { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, e->buf, side, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
-        { ProfScope ps(e, 3, st); net_stage(e, st, NET_CONV4, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+        { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, nb, side, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+        { ProfScope ps(e, 3, st); net_stage(e, st, NET_CONV4, w, nb, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
     }
-    { ProfScope ps(e, 4, st); net_stage(e, st, NET_FC, w, e->buf, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
-    { ProfScope ps(e, 5, st); net_stage(e, st, NET_HEADS, w, e->buf, nullptr, legal_masks, log_policy_out, value_out, priors_out, nullptr, n); }
-    e->buf.write_hidden = 0;
+    { ProfScope ps(e, 4, st); net_stage(e, st, NET_FC, w, nb, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n); }
+    { ProfScope ps(e, 5, st); net_stage(e, st, NET_HEADS, w, nb, nullptr, legal_masks, log_policy_out, value_out, priors_out, nullptr, n); }
     HIP_TRY(hipGetLastError());
     return NNB_OK;
 }
@@ -1169,6 +1171,21 @@ int nnb_profile_enable(nnb_engine *e, int on) {
         e->prof_events = true;
     }
     e->prof_on = on != 0;
+    return NNB_OK;
+}
+
+int nnb_profile_clocks(nnb_engine *e, void *stream, double *mhz_out) {
+    if (!e) return fail(NNB_ERR_ARG, "engine is null");
+    if (!mhz_out) return fail(NNB_ERR_ARG, "mhz_out is null");
+    unsigned long long h[8];
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(h, e->buf.clk, sizeof h, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int k = 0; k < 2; ++k) {
+        const unsigned long long *c = h + 4 * k;
+        // the wall clock ticks at 100 MHz
+        mhz_out[k] = (c[3] > c[1] && c[2] > c[0]) ? (double)(c[2] - c[0]) / (double)(c[3] - c[1]) * 100.0 : 0.0;
+    }
     return NNB_OK;
 }
 

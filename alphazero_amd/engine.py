@@ -332,6 +332,13 @@ class Engine:
         check(self.lib.nnb_profile_enable(self.handle, int(on)), "nnb_profile_enable")
         check(self.lib.nnb_profile_reset(self.handle), "nnb_profile_reset")
 
+    def profile_clocks(self) -> dict:
+        """Shader clock (MHz) of the last profiled convolution and linear-layer launch (0.0 if none was stamped)."""
+        mhz = (C.c_double * 2)()
+        with torch.cuda.device(self.device):
+            check(self.lib.nnb_profile_clocks(self.handle, self._stream(), mhz), "nnb_profile_clocks")
+        return {"conv": mhz[0], "fc": mhz[1]}
+
     def profile_report(self) -> dict:
         out = {}
         for i, name in enumerate(PROFILE_CLASSES):

@@ -267,6 +267,7 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed_rank0 = elapsed
     prof = engine.profile_report()
+    clocks = engine.profile_clocks() if args.precision == "f32s" else {}
     engine.profile(False)
 
     def timed(fn, note):
@@ -290,7 +291,7 @@ def main():
         one_step(engine, p1, "one_chain", gather=False)
         engine.profile(True)
         st1 = one_step(engine, p1, "one_chain", gather=False)
-        prof_one = (engine.profile_report(), st1)
+        prof_one = (engine.profile_report(), st1, engine.profile_clocks() if args.precision == "f32s" else {})
         engine.profile(False)
     if extras:
         extra["single_round_identical_games"] = timed(
@@ -421,6 +422,7 @@ def main():
                          "mfma_per_product": mfma_per_product,
                          "issued_frac": achieved * mfma_per_product / PEAK_TFLOPS[args.precision],
                          "concurrent_chains": chains,
+                         "shader_clock_mhz": {k: round(v) for k, v in clocks.items()}, "peak_assumes_mhz": 2400,
                          "region_net_tflops": totals["net_leaves"] * sum(FLOP_PER_LEAF.values()) / (elapsed_rank0 * 1e12),
                          "region_frac": totals["net_leaves"] * sum(FLOP_PER_LEAF.values()) / (elapsed_rank0 * 1e12)
                                         / PEAK_TFLOPS[args.precision]},
@@ -435,7 +437,7 @@ def main():
                 "launch durations by HIP events on each chain's own stream inside the timed region: a launch there shares "
                 "the chip with the other chain's kernels, so its duration overstates the time its work takes; region_frac "
                 "is the network's algorithmic FLOPs of the whole timed region over the region's wall time")
-            p1, st1 = prof_one
+            p1, st1, clk1 = prof_one
             lpl = st1["net_leaves"] / max(st1["steps"], 1)
             ms = p1[dom]["avg_ms"]
             ach = lpl * FLOP_PER_LEAF[dom] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -446,6 +448,7 @@ def main():
                 "leaves_per_launch": lpl, "avg_launch_ms": ms,
                 "issued_frac": ach * mfma_per_product / PEAK_TFLOPS[args.precision],
                 "flop_per_leaf": FLOP_PER_LEAF[dom], "mfma_per_product": mfma_per_product,
+                "shader_clock_mhz": {k: round(v) for k, v in clk1.items()}, "peak_assumes_mhz": 2400,
                 "kernel_ms": {k: round(v["avg_ms"], 4) for k, v in p1.items()},
                 "measured": "OUTSIDE the timed region: HIP events on the launch stream over one more step of the same stream of games, run right "
                             "after the timed region with all games in ONE chain, so that every kernel has the chip to "

@@ -387,6 +387,11 @@ int nnb_dirichlet_noise(void *stream, int32_t n, uint64_t seed, const int32_t *g
 int nnb_profile_enable(nnb_engine *engine, int on);
 int nnb_profile_reset(nnb_engine *engine);
 int nnb_profile_get(nnb_engine *engine, int which, double *avg_ms_out, int64_t *launches_out);
+/* Shader clock, in MHz, that the last profiled launch of the convolution kernel (mhz_out[0]) and of the linear
+ * layer (mhz_out[1]) ran at: block 0 of those kernels stamps the shader-cycle counter and the constant 100 MHz
+ * clock at its start and end while profiling is enabled (float32-faithful path; 0 when nothing was stamped).
+ * The matrix peak a roofline is quoted against assumes 2400 MHz.  Synchronous.  No reference counterpart. */
+int nnb_profile_clocks(nnb_engine *engine, void *stream, double *mhz_out);
 
 #ifdef __cplusplus
 }

@@ -109,3 +109,62 @@ def test_small_batch_and_large_batch_kernels_agree_bit_for_bit(rp, precision):
                 assert torch.equal(eng.activations(layer, min(n, 100)), ref[:min(n, 100)]), (n, layer)
     finally:
         eng.close()
+
+
+def test_rows_beyond_four_gigabytes_of_activations(rp):
+    """One activation row of the float32-faithful linear layer is 46 080 bytes, so from row 93 207 on a row's byte
+    offset no longer fits 32 bits.  The kernels address a row block through a 64-bit base: positions evaluated in the
+    last rows of a 93 500-row batch must come out exactly as in a small batch."""
+    import torch
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.selfplay import random_openings
+    n = 93500
+    eng = Engine(max_games=n, max_sims=2, precision="f32s")
+    try:
+        eng.load_state_dict(rp.seeded_state_dict(0), 0)
+        sb, sp = random_openings(eng, 300, 6, seed=13)
+        side300 = np.where(sp[:, None] == 1, sb, sb[:, ::-1]).astype(np.uint64)
+        side = side300[np.arange(n) % 300]
+        logp, value, _ = eng.net_forward(side)
+        small_logp, small_value, _ = eng.net_forward(side300)
+        idx = torch.arange(n, device=logp.device) % 300
+        assert torch.equal(logp, small_logp[idx]) and torch.equal(value, small_value[idx])
+        assert (n - 1) * 46080 >= 2 ** 32
+    finally:
+        eng.close()
+
+
+def test_linear_layer_hand_off_under_uneven_load(rp):
+    """The two K halves of a linear-layer tile meet inside the launch: the block that arrives second waits for the
+    first one's partial sums.  With another stream keeping part of the chip busy the two arrive far apart, on
+    whatever CUs are free; outputs and hidden activations must still be those of a quiet run, bit for bit, for
+    batch sizes that use both kernel forms and all row-tile counts."""
+    import torch
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.selfplay import random_openings
+    eng = Engine(max_games=3000, max_sims=4, precision="f32s")
+    try:
+        eng.load_state_dict(rp.seeded_state_dict(0), 0)
+        sb, sp = random_openings(eng, 3000, 6, seed=3)
+        side = np.where(sp[:, None] == 1, sb, sb[:, ::-1]).astype(np.uint64)
+        side_t = torch.from_numpy(side.view(np.int64)).to(eng.device)
+        sizes = (3000, 2048, 1100, 700, 257, 256, 33)
+        quiet = {}
+        for n in sizes:
+            lp, v, _ = eng.net_forward(side_t[:n])
+            quiet[n] = (lp.clone(), v.clone(), eng.activations(4, min(n, 64)).clone())
+        noise_stream = torch.cuda.Stream()
+        a = torch.randn(4096, 4096, device=eng.device)
+        for rep in range(6):
+            with torch.cuda.stream(noise_stream):
+                for _ in range(6 + 5 * rep):
+                    a = torch.tanh(a @ a * 1e-3)                   # a few milliseconds of somebody else's kernels
+            for n in sizes:
+                lp, v, _ = eng.net_forward(side_t[:n])
+                assert torch.equal(lp, quiet[n][0]) and torch.equal(v, quiet[n][1]), (rep, n)
+                assert torch.equal(eng.activations(4, min(n, 64)), quiet[n][2]), (rep, n)
+        torch.cuda.synchronize()
+        # a search reads the engine's count of waits that ran out and fails loudly if there was one
+        eng.search(sb[:8], sp[:8], eng.params(4, 1.4, evaluator="net"))
+    finally:
+        eng.close()

@@ -1,0 +1,47 @@
+"""Builds libnnb variants with other compile-time settings, for timing sweeps on one box:
+
+    python tools/build_variants.py                 # tools/variants/libnnb_<name>.so
+    NNB_LIB=tools/variants/libnnb_ts3.so python bench.py --steps 5 --warmup 2 --no-extra-lines --no-cpu-baseline
+
+Every variant has the ABI of the product library (alphazero_amd/_lib.py loads whatever NNB_LIB names)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from alphazero_amd.build import COMMON, CSRC, SOURCES, _hipcc  # noqa: E402
+
+VARIANTS = {
+    "ts3": ["-DNNB_TERMINAL_SIMS_PER_STEP=3"],
+    "ts10": ["-DNNB_TERMINAL_SIMS_PER_STEP=10"],
+    "look32": ["-DNNB_LOOK_ROUNDS=32"],
+    "look128": ["-DNNB_LOOK_ROUNDS=128"],
+    "look256": ["-DNNB_LOOK_ROUNDS=256"],
+}
+AFFECTED = {"NNB_TERMINAL_SIMS_PER_STEP": "tree_kernels.hip", "NNB_LOOK_ROUNDS": "nnb_api.hip"}
+
+
+def main():
+    out = os.path.join(ROOT, "tools", "variants")
+    os.makedirs(out, exist_ok=True)
+    hipcc = _hipcc()
+    names = sys.argv[1:] or list(VARIANTS)
+    for name in names:
+        defs = VARIANTS[name]
+        objs = []
+        for src, extra in SOURCES:
+            base = os.path.join(CSRC, src.replace(".hip", ".o"))
+            if any(AFFECTED[d[2:].split("=")[0]] == src for d in defs):
+                obj = os.path.join(out, f"{name}_{src.replace('.hip', '.o')}")
+                subprocess.check_call([hipcc, *COMMON, *extra, *defs, "-c", os.path.join(CSRC, src), "-o", obj])
+            else:
+                obj = base                                   # the product build's object
+            objs.append(obj)
+        lib = os.path.join(out, f"libnnb_{name}.so")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+        print(lib, flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -78,7 +78,7 @@ int main(int argc, char **argv) {
     report("conv 8x9->9x10", us, (double)n * 2 * 128 * 90 * 2048);
     us = time_it([&] {
         conv_pair_split_kernel<CS_NB, 4, 8, false><<<cdiv_sp(n, CS_NB), 256, CPS_SPLIT_LDS, 0>>>(
-            side, w0h, w0l, bias, w2h, w2l, bias, w2h, w2l, bias, sc, nullptr, nullptr, act3, inv_o, nullptr, n);
+            side, w0h, w0l, bias, w2h, w2l, bias, w2h, w2l, bias, sc, nullptr, nullptr, act3, inv_o, nullptr, n, nullptr);
     });
     {
         unsigned long long h[8]; CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sp_clk), sizeof h));
@@ -127,7 +127,7 @@ int main(int argc, char **argv) {
         constexpr int BR = decltype(BRc)::value, ABL = decltype(ABLc)::value;
         float t = time_it([&] {
             int groups = cdiv_sp(cdiv_sp(rows, 128), 32);
-            fc_split_kernel<BR, ABL><<<256 * groups, 256, 0, 0>>>(a3, inv, wfh, wfl, sc, fin, nullptr, rows, n, 0);
+            fc_split_kernel<BR, ABL><<<256 * groups, 256, 0, 0>>>(a3, inv, wfh, wfl, sc, fin, nullptr, rows, n, 0, nullptr);
         });
         unsigned long long h[8]; CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sp_clk), sizeof h));
         printf("linear 11520->1024, %4d rows, ring %d, ablate %2d: %8.1f us  %7.1f TFLOP/s  block %llu cycles, clock %.0f MHz\n", rows, BR, ABL, t,

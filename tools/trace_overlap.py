@@ -29,6 +29,7 @@ tot = sum(hist.values())
 for k, v in sorted(hist.items(), key=lambda kv: -kv[1]):
     print(f"{v / tot * 100:6.2f} %  in flight: {' + '.join(k) if k else '(nothing)'}")
 print("launches:", len(ev), "span ms:", tot / 1e6)
+idle = hist.get((), 0)
 # idle gaps: how many, how long
 gaps = []
 end_max = ev[0][1]
@@ -41,3 +42,6 @@ import statistics
 print("idle gaps:", len(gaps), "total ms:", sum(gaps) / 1e6, "median us:", statistics.median(gaps) / 1e3 if gaps else 0,
       "over 100 us:", sum(1 for g in gaps if g > 1e5), "their total ms:", sum(g for g in gaps if g > 1e5) / 1e6,
       "largest ms:", [round(g / 1e6, 2) for g in gaps[-5:]])
+if gaps:
+    # the largest gap is the host between two bench steps (fence, all-gather, bookkeeping), not the lock-step loop
+    print(f"nothing in flight, the largest gap left out: {(idle - gaps[-1]) / (tot - gaps[-1]) * 100:.2f} % of the span")
