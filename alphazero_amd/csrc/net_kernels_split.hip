@@ -1020,9 +1020,9 @@ __global__ __launch_bounds__(256, 2) void conv_pair_split_small_kernel(const u64
 // A slabs of 64 k (128 bytes of hi and 128 of lo per row) go global -> registers four slabs ahead and
 // registers -> LDS two slabs ahead (three LDS buffers of 32 KB, one barrier per slab).  The two K
 // halves of a tile meet in fc_split_finish, which adds them, the bias and the ReLU and reduces the
-// row against the head rows.  Block order as in fc_f16_kernel: blocks that share blockIdx % 8 (one
-// XCD, as blocks are dealt out today: a matter of speed only) cover 4 row blocks x (4 column blocks
-// x 2 K halves), so the two halves of a tile share an L2.
+// row against the head rows.  Blocks that share blockIdx % 8 (one XCD, as blocks are dealt out
+// today: a matter of speed only) cover 8 row blocks x (2 column blocks x 2 K halves), so the two
+// halves of a tile share an L2 and an L2 fetches half the weight matrix.
 // ---------------------------------------------------------------------------
 constexpr int FCS_K = 11520, FCS_N = 1024, FCS_BK = 64, FCS_SPLIT = 2;
 constexpr int FCS_ROW_BYTES = 90 * 512;                      // one activation row: 90 cells x (128 hi + 128 lo halves)
@@ -1189,8 +1189,13 @@ __device__ __forceinline__ void fc_split_tile(const u32x4 *__restrict__ a, const
     const int x = bid & 7, i = bid >> 3;
     const int per = 8 * mbx;
     const int grp = i / per, ii = i - grp * per;
-    const int mb = (grp * 8 + x) * mbx + ii % mbx;
-    const int nb = (ii / mbx) & 3, ksp = ii / (4 * mbx);
+    // XCDs 0-3 (blocks with blockIdx % 8 < 4, as blocks are dealt out today: a matter of traffic only) take column
+    // blocks 0-1, XCDs 4-7 column blocks 2-3; inside a half, XCD x & 3 takes a quarter of the group's row blocks.
+    // An XCD's L2 then fetches HALF the weight matrix, every byte serving 2*mbx row blocks, and each activation row
+    // is fetched by two XCDs: for 2048 rows 184 + 189 MB instead of the 92 + 377 MB of "one XCD, all columns".
+    const int q = 2 * mbx;                                   // row blocks per XCD
+    const int mb = grp * 8 * mbx + (x & 3) * q + ii % q;
+    const int nb = (x >> 2) * 2 + ((ii / q) & 1), ksp = ii / (2 * q);
     const int row0 = mb * (32 * MTR);
     if (row0 >= count) return;
     NNB_SP_STAMP(0) NNB_SP_WALL(5)

@@ -1,7 +1,9 @@
 #!/bin/bash
 # Fabric-side read bytes of the float32-faithful linear layer as a function of the row count.  The kernel uses row
-# tiles of 32*t rows, t = ceil(rows / 1024), and deals its row blocks to the 8 XCDs in groups of four, so the row count
-# decides how many XCDs take part; each of them fetches the whole weight matrix once.  One FETCH_SIZE pass per size.
+# tiles of 32*t rows, t = ceil(rows / 1024); XCDs 0-3 take the first two 256-column blocks, XCDs 4-7 the other two, and
+# XCD x & 3 takes row blocks 8*(x & 3) .. +7 of the 32 a group of 256 blocks covers.  So the row count decides how many
+# XCDs take part; each of them fetches half the weight matrix once, and every activation row is fetched by two XCDs
+# (plus, per row, the 2 KB of partial sums one K half hands to the other).  One FETCH_SIZE pass per size.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 out=gpurun_out/fc_fetch
@@ -16,9 +18,10 @@ vals = [float(r["Counter_Value"]) for f in glob.glob(d + "/**/*counter_collectio
 act, w = n * 46080 / 1e6, 47.2
 t = (n + 1023) // 1024
 row_blocks = (n + 32 * t - 1) // (32 * t)
-xcds = min(8, (row_blocks + 3) // 4)
-print(f"rows {n}: {len(vals)} launches, FETCH_SIZE x 2 = {2 * sum(vals) / len(vals) * 1024 / 1e6:.1f} MB per launch; "
-      f"activations {act:.1f} MB + weights {w} MB x {xcds} XCDs = {act + w * xcds:.1f} MB")
+xcds = 2 * min(4, (row_blocks + 7) // 8)
+hand = n * 2048 / 1e6
+print(f"rows {n}: {len(vals)} launches, FETCH_SIZE x 2 = {2 * sum(vals) / len(vals) * 1024 / 1e6:.1f} MB per launch; model: "
+      f"activations 2 x {act:.1f} MB + weights {w / 2} MB x {xcds} XCDs + hand-off {hand:.1f} MB = {2 * act + w / 2 * xcds + hand:.1f} MB")
 PY
   rm -rf "$out/n$n"
 done
