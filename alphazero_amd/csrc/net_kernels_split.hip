@@ -144,7 +144,11 @@ __device__ __forceinline__ void conv_split_row(f32x16 (&acc)[NACC], u32x4 (&bh)[
                                                const __amdgpu_buffer_rsrc_t &rwh, const __amdgpu_buffer_rsrc_t &rwl, int woff) {
     constexpr int W2 = IW + 2, PB = SP_PB;
     constexpr int T0 = TROWS == 1 ? rows_t0(KH) : 0;
+#ifdef NNB_ABL_SMALL_TILES                                           // (timing experiments only: fewer tiles than the output has)
+    constexpr int NT = TROWS == 1 ? rows_t1(IH, KH) - T0 : (IH == 7 ? NNB_ABL_SMALL_TILES / 10 : NNB_ABL_SMALL_TILES % 10), STEPS = 8 * NT;
+#else
     constexpr int NT = TROWS == 1 ? rows_t1(IH, KH) - T0 : (IH + TROWS) / TROWS, STEPS = 8 * NT;
+#endif
     constexpr int TS = TROWS * W2 * PB;                          // bytes between consecutive tiles in the image
     static_assert(T0 + NT <= NACC, "one accumulator per tile");
     static_assert(STEPS % ARING == 0, "ring depth must divide the fragment pairs per tap");
@@ -1013,6 +1017,330 @@ __global__ __launch_bounds__(256, 2) void conv_pair_split_small_kernel(const u64
 }
 
 // ---------------------------------------------------------------------------
+// All three convolutions, ONE board per block, 16-cell tiles (conv_board_split_kernel).
+//
+// The board's output cells are taken row-major, 16 at a time, as the rows of v_mfma_f32_16x16x32_f16 tiles: 72 cells
+// = 5 tiles for the 7x8 -> 8x9 layer, 90 cells = 6 tiles for 8x9 -> 9x10 (the 3-boards-per-block form fills 27 and 30
+// of its 32 rows, and a 32-row tile of one board would waste a quarter of the last one).  A tile spans at most three
+// output rows, so the (tile, kernel row) pairs that read nothing but padding are still known at compile time and
+// skipped.  The image of one board takes 72 KB of LDS and a wave at most 256 registers, so TWO blocks share a CU:
+// while one is in its prologue or one of its epilogues (no matrix work), the other one's waves keep the matrix pipe
+// busy - on a power-capped chip more pipes busy at a lower clock deliver more than fewer at a higher one.  The price
+// is the weight stream: every block reads both layers' weights from L2 for one board instead of three.
+// Wave w owns output channels 32w .. 32w+31 as two 16-column tiles.  Operand layouts of the instruction: lane l
+// supplies row l % 16 of A and column l % 16 of B for k = 8 * (l / 16) .. + 7, and holds D[4 * (l / 16) + r][l % 16].
+// One k-step is 32 input channels; the weight layout [tap][c / 16][(c % 16) / 8][n][c % 8] is the 32x32x16 one read
+// two 16-channel steps at a time.
+// ---------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int IH, int IW>
+struct BoardGeom {
+    static constexpr int OH = IH + 1, OW = IW + 1, NC = OH * OW, NT = (NC + 15) / 16, W2 = IW + 2, LEAD = 2 + 2 * W2;
+    static constexpr int NPOS = conv_small_positions(IH, IW);
+    static constexpr int row_first(int t) { return (16 * t) / OW; }
+    static constexpr int row_last(int t) { return (16 * t + 15 < NC ? 16 * t + 15 : NC - 1) / OW; }
+    // kernel row kh of tile t reads at least one input row
+    static constexpr bool live(int t, int kh) { return row_last(t) + kh - 2 >= 0 && row_first(t) + kh - 2 < IH; }
+};
+
+// All four taps of kernel row KH for the live tiles.  Fragments of one (tap, k-step) are read one step ahead into the
+// other of two register sets; weights BRING - 1 steps ahead.  acc[t][j]: tile t, channel tile j.
+template <int IH, int IW, int NT, int BRING, int KH>
+__device__ __forceinline__ void conv_board_row(f32x4 (&acc)[NT][2], u32x4 (&bh)[BRING][2], u32x4 (&bl)[BRING][2],
+                                               const unsigned char *smem, const int (&tbase)[NT],
+                                               const __amdgpu_buffer_rsrc_t &rwh, const __amdgpu_buffer_rsrc_t &rwl, int woff) {
+    using G = BoardGeom<IH, IW>;
+    static_assert(NT == G::NT, "one accumulator pair per tile");
+    constexpr int W2 = G::W2, PB = SP_PB;
+    u32x4 ah[2][NT], al[2][NT];
+    const unsigned char *p0 = smem + ((KH - 2) * W2 - 2) * PB;
+    static_for<NT>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+        if constexpr (G::live(t, KH)) {
+            ah[0][t] = *reinterpret_cast<const u32x4 *>(p0 + tbase[t]);
+            al[0][t] = *reinterpret_cast<const u32x4 *>(p0 + tbase[t] + SP_LO);
+        }
+    });
+#pragma unroll 1
+    for (int kw = 0; kw < 4; ++kw) {
+        const unsigned char *pv = p0 + kw * PB;
+        const bool more = kw < 3;
+        const int step0 = (KH * 4 + kw) * 4;
+        static_for<4>([&](auto Kc) __attribute__((always_inline)) {
+            constexpr int ks = decltype(Kc)::value;
+            constexpr int cur = ks & 1, nxt = cur ^ 1;
+            constexpr int slot = ks % BRING, fill = (ks + BRING - 1) % BRING;
+            static_assert(4 % BRING == 0, "the weight ring must divide the k-steps of a tap");
+            {
+                const int sn = (step0 + ks + BRING - 1) * 8192;      // past the layer's last step: zeros, never used
+                bh[fill][0] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, sn, 0);
+                bh[fill][1] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff + 256, sn, 0);
+                bl[fill][0] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, sn, 0);
+                bl[fill][1] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff + 256, sn, 0);
+            }
+            static_for<NT>([&](auto T) __attribute__((always_inline)) {       // fragments of the next step
+                constexpr int t = decltype(T)::value;
+                if constexpr (G::live(t, KH)) {
+                    if constexpr (ks < 3) {
+                        ah[nxt][t] = *reinterpret_cast<const u32x4 *>(pv + tbase[t] + (ks + 1) * 64);
+                        al[nxt][t] = *reinterpret_cast<const u32x4 *>(pv + tbase[t] + (ks + 1) * 64 + SP_LO);
+                    } else if (more) {
+                        ah[nxt][t] = *reinterpret_cast<const u32x4 *>(pv + PB + tbase[t]);
+                        al[nxt][t] = *reinterpret_cast<const u32x4 *>(pv + PB + tbase[t] + SP_LO);
+                    }
+                }
+            });
+            const half8 wh0 = as_half8(bh[slot][0]), wh1 = as_half8(bh[slot][1]);
+            const half8 wl0 = as_half8(bl[slot][0]), wl1 = as_half8(bl[slot][1]);
+            static_for<NT>([&](auto T) __attribute__((always_inline)) {
+                constexpr int t = decltype(T)::value;
+                if constexpr (G::live(t, KH)) {
+                    const half8 xh = as_half8(ah[cur][t]), xl = as_half8(al[cur][t]);
+                    // per accumulator: hi*lo, lo*hi, hi*hi, in this order; the two channel tiles alternate
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl0, acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl1, acc[t][1], 0, 0, 0);
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wh0, acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wh1, acc[t][1], 0, 0, 0);
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wh0, acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wh1, acc[t][1], 0, 0, 0);
+                }
+            });
+        });
+    }
+}
+
+// One 128->128 layer over the board's image at `smem`: accumulators cleared, weights primed, four kernel rows.
+template <int IH, int IW, int NT, int BRING>
+__device__ __forceinline__ void conv_board_layer(f32x4 (&acc)[NT][2], const unsigned char *smem,
+                                                 const u32x4 *wph, const u32x4 *wpl, int lane, int wave) {
+    using G = BoardGeom<IH, IW>;
+    static_assert(NT == G::NT, "one accumulator pair per tile");
+    const int m = lane & 15, kg = lane >> 4;
+    int tbase[G::NT];
+    static_for<G::NT>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+        int c = 16 * t + m;
+        c = c < G::NC ? c : G::NC - 1;                           // rows past the last cell repeat it
+        tbase[t] = (G::LEAD + (c / G::OW) * G::W2 + c % G::OW) * SP_PB + kg * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc[t][0][r] = 0.f; acc[t][1][r] = 0.f; }
+    });
+    const __amdgpu_buffer_rsrc_t rwh = conv_weight_rsrc(wph), rwl = conv_weight_rsrc(wpl);
+    const int woff = (kg * 128 + wave * 32 + m) * 16;           // + 256 bytes: the second channel tile
+    u32x4 bh[BRING][2], bl[BRING][2];
+#pragma unroll
+    for (int i = 0; i < BRING - 1; ++i) {
+        bh[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, i * 8192, 0);
+        bh[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff + 256, i * 8192, 0);
+        bl[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, i * 8192, 0);
+        bl[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff + 256, i * 8192, 0);
+    }
+    conv_board_row<IH, IW, NT, BRING, 0>(acc, bh, bl, smem, tbase, rwh, rwl, woff);
+    conv_board_row<IH, IW, NT, BRING, 1>(acc, bh, bl, smem, tbase, rwh, rwl, woff);
+    conv_board_row<IH, IW, NT, BRING, 2>(acc, bh, bl, smem, tbase, rwh, rwl, woff);
+    conv_board_row<IH, IW, NT, BRING, 3>(acc, bh, bl, smem, tbase, rwh, rwl, woff);
+}
+
+// v = ReLU(acc * k + bias) in place; returns this lane's maximum over the board's cells
+template <int NT, int NC>
+__device__ __forceinline__ float conv_board_finish(f32x4 (&acc)[NT][2], float k, const float (&bv)[2], int kg) {
+    float mx = 0.f;
+    static_for<NT>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool valid = 16 * t + 15 < NC || 16 * t + 4 * kg + r < NC;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float v = fmaxf(__builtin_fmaf(acc[t][j][r], k, bv[j]), 0.f);
+                acc[t][j][r] = v;
+                mx = fmaxf(mx, valid ? v : 0.f);
+            }
+        }
+    });
+    return mx;
+}
+
+// Quantised with the board's scale, hi / lo into LDS: output cell c = (row, column) goes to position
+// LEADO + row * RSO + column.  A lane swaps its (hi, lo) pair with the neighbouring channel's lane (same cell): the
+// even lane stores both hi halves, the odd lane both lo halves, one 32-bit word each (as conv_split_store).
+template <int NT, int NC, int OW, int RSO, int LEADO>
+__device__ __forceinline__ void conv_board_store(const f32x4 (&acc)[NT][2], float sc_out, unsigned *ldsw, int wave, int lane) {
+    const int m = lane & 15, kg = lane >> 4, odd = lane & 1;
+    const unsigned psel = odd ? 0x03020706u : 0x05040100u;
+    static_for<NT>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * t + 4 * kg + r;
+            const int pos = LEADO + (c / OW) * RSO + c % OW;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+                half2v pr;
+                const float x = acc[t][j][r] * sc_out;
+                pr[0] = (_Float16)x;
+                pr[1] = (_Float16)(x - (float)pr[0]);
+                const unsigned own = __builtin_bit_cast(unsigned, pr);
+                const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);   // lane ^ 1
+                const int ch = wave * 32 + 16 * j + m;
+                if (16 * t + 15 < NC || c < NC)
+                    ldsw[pos * (SP_PB / 4) + (ch >> 1) + (odd ? SP_LO / 4 : 0)] = __builtin_amdgcn_perm(other, own, psel);
+            }
+        }
+    });
+}
+
+template <int BRING, bool WRITE_MID>
+__global__ __launch_bounds__(256, 2) void conv_board_split_kernel(const u64 *__restrict__ side,
+                                                                  const u32x4 *__restrict__ w0h, const u32x4 *__restrict__ w0l,
+                                                                  const float *__restrict__ b0,
+                                                                  const u32x4 *__restrict__ w2h, const u32x4 *__restrict__ w2l,
+                                                                  const float *__restrict__ bias2,
+                                                                  const u32x4 *__restrict__ w4h, const u32x4 *__restrict__ w4l,
+                                                                  const float *__restrict__ bias4,
+                                                                  const SplitScales *__restrict__ sc,
+                                                                  u32x4 *__restrict__ mid, float *__restrict__ mid_inv_scale,
+                                                                  u32x4 *__restrict__ out, float *__restrict__ out_inv_scale,
+                                                                  const int32_t *__restrict__ count_ptr, int n_fixed,
+                                                                  unsigned long long *__restrict__ clk) {
+    using G1 = BoardGeom<7, 8>;
+    using G2 = BoardGeom<8, 9>;
+    constexpr int PB = SP_PB;
+    constexpr int IW1 = 8, IP1 = 56, W21 = G1::W2, LEAD1 = G1::LEAD, NPOS1 = G1::NPOS;
+    constexpr int IH2 = 8, IW2 = 9, IP2 = 72, W22 = G2::W2, LEAD2 = G2::LEAD, NPOS2 = G2::NPOS;
+    constexpr int OP2 = G2::NC;
+    constexpr int REGION = (NPOS2 > NPOS1 ? (NPOS2 > OP2 ? NPOS2 : OP2) : (NPOS1 > OP2 ? NPOS1 : OP2)) * PB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4 *lds = reinterpret_cast<u32x4 *>(smem_raw);
+    float *s_max = reinterpret_cast<float *>(smem_raw + REGION);     // [4 waves]
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter(); clk[1] = wall_clock64(); }
+
+    const int count = batch_count_sp(count_ptr, n_fixed);
+    const int board = blockIdx.x;
+    if (board >= count) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, nt = tid >> 6, m = lane & 31, h = lane >> 5;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    NNB_SP_STAMP(0) NNB_SP_WALL(5)
+
+    // ---- leaf encode + 2->128 layer into the first image (32x32x16 tiles of 32 cells, as in the other forms) ----
+    for (int e = tid; e < NPOS1 * SP_RS; e += 256) lds[e] = zero4;
+    __syncthreads();
+    {
+        half8 bwh[2], bwl[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            bwh[pl] = as_half8(w0h[(nt * 32 + m) * 4 + 2 * pl + h]);
+            bwl[pl] = as_half8(w0l[(nt * 32 + m) * 4 + 2 * pl + h]);
+        }
+        const float bv_in = b0[nt * 32 + m];
+        const float inv_sw0 = sc->inv_sw0, sa1 = sc->sa1;
+        _Float16 *ldsh_in = reinterpret_cast<_Float16 *>(smem_raw);
+        const u64 planes[2] = {side[2 * board], side[2 * board + 1]};
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int pos = mt * 32 + m, oh = pos >> 3, ow = pos & 7;
+            f32x16 c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                half8 a;
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int ih = oh + 2 * h + rr - 2;
+                    u64 t = (unsigned)ih < 6u ? (planes[pl] >> (5 - ih)) & c4::kBottomMask : 0;
+                    unsigned row = (unsigned)((t * 0x41041041040ULL) >> 42) & 0x7F;
+                    unsigned nib = ((row << 2) >> ow) & 0xF;
+#pragma unroll
+                    for (int kw = 0; kw < 4; ++kw) a[rr * 4 + kw] = ((nib >> kw) & 1) ? (_Float16)1.0f : (_Float16)0.0f;
+                }
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bwl[pl], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bwh[pl], c, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (p < IP1) {
+                    const float v = fmaxf(__builtin_fmaf(c[r], inv_sw0, bv_in), 0.f);
+                    _Float16 hi, lo;
+                    split_half(v * sa1, hi, lo);
+                    _Float16 *dst = ldsh_in + (LEAD1 + (p / IW1) * W21 + p % IW1) * (PB / 2) + nt * 32 + m;
+                    dst[0] = hi;
+                    dst[128] = lo;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    NNB_SP_STAMP(1)
+
+    const int m16 = lane & 15, kg = lane >> 4;
+    float k2;                                                    // 1 / (scale of the middle activations * weight scale)
+    // ---- first 128->128 layer ----
+    {
+        f32x4 acc[G1::NT][2];
+        conv_board_layer<7, 8, G1::NT, BRING>(acc, smem_raw, w2h, w2l, lane, nt);
+        NNB_SP_STAMP(2)
+        const float k1 = sc->inv_sa1 * sc->inv_sw2;
+        const float bv[2] = {bias2[nt * 32 + m16], bias2[nt * 32 + 16 + m16]};
+        float v = conv_board_finish<G1::NT, G1::NC>(acc, k1, bv, kg);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+        if (lane == 0) s_max[nt] = v;
+        __syncthreads();                                         // every wave is done with the first image
+        float sinv;
+        const float sout = pow2_scale(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])), sinv);
+        // the second image: zeros wherever there is no pixel, the quantised activations where there is one
+        constexpr int TOP = LEAD2, BOT = NPOS2 - (LEAD2 + IH2 * W22), NPAD = TOP + 2 * IH2 + BOT;
+        static_assert(NPAD + IP2 == NPOS2, "every position of the image is a pixel or padding");
+        for (int e = tid; e < NPAD * 32; e += 256) {
+            const int kk = e >> 5, q = e & 31;
+            const int pos = kk < TOP ? kk
+                          : kk < TOP + 2 * IH2 ? LEAD2 + ((kk - TOP) >> 1) * W22 + IW2 + ((kk - TOP) & 1)
+                                               : LEAD2 + IH2 * W22 + (kk - TOP - 2 * IH2);
+            lds[pos * SP_RS + q] = zero4;
+        }
+        conv_board_store<G1::NT, G1::NC, G1::OW, W22, LEAD2>(acc, sout, reinterpret_cast<unsigned *>(smem_raw), nt, lane);
+        k2 = sinv * sc->inv_sw4;
+        if constexpr (WRITE_MID) {
+            if (tid == 0) mid_inv_scale[board] = sinv;
+        }
+        __syncthreads();                                         // the second image is complete (s_max may be reused)
+        if constexpr (WRITE_MID) {
+            u32x4 *dst = mid + (size_t)board * IP2 * 32;
+            for (int e = tid; e < IP2 * 32; e += 256) {
+                const int p = e >> 5, q = e & 31;
+                dst[e] = lds[(LEAD2 + (p / IW2) * W22 + p % IW2) * SP_RS + q];
+            }
+        }
+    }
+    NNB_SP_STAMP(4)
+
+    // ---- second 128->128 layer ----
+    f32x4 acc[G2::NT][2];
+    conv_board_layer<8, 9, G2::NT, BRING>(acc, smem_raw, w4h, w4l, lane, nt);
+    NNB_SP_STAMP(7)
+    const float bv[2] = {bias4[nt * 32 + m16], bias4[nt * 32 + 16 + m16]};
+    float v = conv_board_finish<G2::NT, G2::NC>(acc, k2, bv, kg);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    if (lane == 0) s_max[nt] = v;
+    __syncthreads();                                             // every wave is done with the second image
+    float sinv;
+    const float sout = pow2_scale(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])), sinv);
+    conv_board_store<G2::NT, G2::NC, G2::OW, G2::OW, 0>(acc, sout, reinterpret_cast<unsigned *>(smem_raw), nt, lane);
+    __syncthreads();
+    u32x4 *dst = out + (size_t)board * OP2 * 32;
+    for (int e = tid; e < OP2 * 32; e += 256) dst[e] = lds[(e >> 5) * SP_RS + (e & 31)];
+    if (tid == 0) out_inv_scale[board] = sinv;
+    NNB_SP_STAMP(3) NNB_SP_WALL(6)
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[2] = __builtin_readcyclecounter(); clk[3] = wall_clock64(); }
+}
+
+// ---------------------------------------------------------------------------
 // linear 11520->1024 (network.py:36-39,46-47) with split operands, split in two halves of K.
 // Block tile (32*MTR) rows x 256 columns, 4 waves (one per SIMD); wave w owns columns 64w..64w+63
 // (two 32-column tiles) for all row tiles, so one k-step of 16 is 8 fragment reads from LDS (hi and
@@ -1495,6 +1823,9 @@ static inline int cdiv_sp(int a, int b) { return (a + b - 1) / b; }
 // block).  Measured whole forward passes, small / large forms: 128 rows 86 / 176 us, 256 rows 129 / 181 us,
 // 384 rows 198 / 193 us, 512 rows 246 / 198 us (tools/net_latency.py).
 constexpr int kSplitSmallConv = 256, kSplitSmallFc = 256;
+#ifndef NNB_CONV_BOARD
+#define NNB_CONV_BOARD 1
+#endif
 constexpr int CS_NB = 3;
 constexpr size_t C2S_SPLIT_LDS = conv_split_lds_bytes(7, 8, CS_NB);
 constexpr size_t C4S_SPLIT_LDS = conv_split_lds_bytes(8, 9, CS_NB);
@@ -1502,7 +1833,13 @@ constexpr size_t CPS_SPLIT_LDS = conv_pair_lds_bytes(CS_NB);
 static_assert(C4S_SPLIT_LDS <= 160 * 1024, "the image of one block must fit the LDS of a CU");
 
 hipError_t prepare_net_kernels_split() {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rows_split_kernel<7, 8, CS_NB, 4, 8, true>),
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_board_split_kernel<4, false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_pair_small_lds_bytes());
+    if (err != hipSuccess) return err;
+    err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_board_split_kernel<4, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_pair_small_lds_bytes());
+    if (err != hipSuccess) return err;
+    err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rows_split_kernel<7, 8, CS_NB, 4, 8, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C2S_SPLIT_LDS);
     if (err != hipSuccess) return err;
     err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rows_split_kernel<8, 9, CS_NB, 4, 8, false>),
@@ -1554,6 +1891,13 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
             b.act2_inv, count_ptr, n_max, side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b);
         break;
     case NET_CONV_PAIR:         // both 128->128 layers (and the 2->128 one) in one launch; act2 stays in LDS
+#if NNB_CONV_BOARD
+        conv_board_split_kernel<4, false><<<n_max, 256, conv_pair_small_lds_bytes(), st>>>(
+            side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
+            (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b,
+            w.sp_scales, nullptr, nullptr, a3, b.act3_inv, count_ptr, n_max, b.clk);
+        break;
+#endif
         if (n_max <= kSplitSmallConv) {                          // one board per block
             conv_pair_split_small_kernel<4, 8, false><<<n_max, 256, conv_pair_small_lds_bytes(), st>>>(
                 side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
@@ -1567,6 +1911,13 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
             nullptr, nullptr, a3, b.act3_inv, count_ptr, n_max, b.clk);
         break;
     case NET_CONV_PAIR_MID:     // the same, and the middle activations are copied out as the two-launch form leaves them
+#if NNB_CONV_BOARD
+        conv_board_split_kernel<4, true><<<n_max, 256, conv_pair_small_lds_bytes(), st>>>(
+            side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
+            (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b,
+            w.sp_scales, a2, b.act2_inv, a3, b.act3_inv, count_ptr, n_max, b.clk);
+        break;
+#endif
         if (n_max <= kSplitSmallConv) {
             conv_pair_split_small_kernel<4, 8, true><<<n_max, 256, conv_pair_small_lds_bytes(), st>>>(
                 side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,

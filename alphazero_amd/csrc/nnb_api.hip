@@ -18,6 +18,11 @@
 
 using namespace nnb;
 
+#ifndef NNB_CONV_BOARD
+#define NNB_CONV_BOARD 1
+#endif
+#define NNB_CONV_BOARD_FORM NNB_CONV_BOARD      // 1: the one-board-per-block convolutions serve every call (no two-launch form)
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -383,7 +388,7 @@ void forward_leaves(nnb_engine *e, hipStream_t st, int weight_set, int batch, in
     const size_t o = (size_t)batch * d.max_games;
     const bool fused_in = e->cfg.net_precision != NNB_NET_F32;     // conv0 is part of the conv2 launch there
     if (!fused_in) { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, nb, d.leaf_side + 2 * o, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
-    if (e->cfg.net_precision == NNB_NET_F32S && !e->separate_convs) {
+    if (e->cfg.net_precision == NNB_NET_F32S && !(e->separate_convs && !NNB_CONV_BOARD_FORM)) {
         // both 128->128 layers in one launch (timed as class 2; class 3 stays empty)
         ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV_PAIR, w, nb, d.leaf_side + 2 * o, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max);
     } else {

@@ -18,8 +18,10 @@ VARIANTS = {
     "look32": ["-DNNB_LOOK_ROUNDS=32"],
     "look128": ["-DNNB_LOOK_ROUNDS=128"],
     "look256": ["-DNNB_LOOK_ROUNDS=256"],
+    "conv3": ["-DNNB_CONV_BOARD=0"],                # the three-boards-per-block convolutions
 }
-AFFECTED = {"NNB_TERMINAL_SIMS_PER_STEP": "tree_kernels.hip", "NNB_LOOK_ROUNDS": "nnb_api.hip"}
+AFFECTED = {"NNB_TERMINAL_SIMS_PER_STEP": ["tree_kernels.hip"], "NNB_LOOK_ROUNDS": ["nnb_api.hip"],
+            "NNB_CONV_BOARD": ["net_kernels_split.hip", "nnb_api.hip"]}
 
 
 def main():
@@ -32,7 +34,7 @@ def main():
         objs = []
         for src, extra in SOURCES:
             base = os.path.join(CSRC, src.replace(".hip", ".o"))
-            if any(AFFECTED[d[2:].split("=")[0]] == src for d in defs):
+            if any(src in AFFECTED[d[2:].split("=")[0]] for d in defs):
                 obj = os.path.join(out, f"{name}_{src.replace('.hip', '.o')}")
                 subprocess.check_call([hipcc, *COMMON, *extra, *defs, "-c", os.path.join(CSRC, src), "-o", obj])
             else:

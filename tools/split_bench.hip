@@ -86,6 +86,28 @@ int main(int argc, char **argv) {
                us, (double)n * 2 * 128 * (72 + 90) * 2048 / (us * 1e-6) / 1e12, h[1] - h[0], h[2] - h[1], h[4] - h[2], h[7] - h[4], h[3] - h[7], h[3] - h[0],
                (double)(h[3] - h[0]) / (double)(h[6] - h[5]) * 100.0);
     }
+    {   // one board per block, 16-cell tiles (two blocks per CU): time, and its output against the form above
+        const int nc = n < 64 ? n : 64;
+        std::vector<float> ref((size_t)nc * 90 * 128), got((size_t)nc * 90 * 128);
+        float *f32; CK(hipMalloc((void **)&f32, ref.size() * 4));
+        launch_split_to_f32(0, act3, inv_o, 90, nc, f32);
+        CK(hipMemcpy(ref.data(), f32, ref.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_board_split_kernel<4, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_pair_small_lds_bytes()));
+        CK(hipMemset(act3, 0, (size_t)n * 90 * 512));
+        float t = time_it([&] {
+            conv_board_split_kernel<4, false><<<n, 256, conv_pair_small_lds_bytes(), 0>>>(
+                side, w0h, w0l, bias, w2h, w2l, bias, w2h, w2l, bias, sc, nullptr, nullptr, act3, inv_o, nullptr, n, nullptr);
+        });
+        launch_split_to_f32(0, act3, inv_o, 90, nc, f32);
+        CK(hipMemcpy(got.data(), f32, got.size() * 4, hipMemcpyDeviceToHost));
+        double worst = 0.0, big = 0.0;
+        for (size_t i = 0; i < ref.size(); ++i) { worst = fmax(worst, fabs((double)ref[i] - got[i])); big = fmax(big, fabs((double)ref[i])); }
+        unsigned long long h[8]; CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sp_clk), sizeof h));
+        printf("both convs, one board per block, 16-cell tiles:  %8.1f us  %7.1f TFLOP/s   block: 2->128 %llu  main1 %llu  epilogue1 %llu  main2 %llu  epilogue2 %llu  total %llu cycles  clock %.0f MHz;  max |diff| to the form above %.3g of max %.3g\n",
+               t, (double)n * 2 * 128 * (72 + 90) * 2048 / (t * 1e-6) / 1e12, h[1] - h[0], h[2] - h[1], h[4] - h[2], h[7] - h[4], h[3] - h[7], h[3] - h[0],
+               (double)(h[3] - h[0]) / (double)(h[6] - h[5]) * 100.0, worst, big);
+    }
     {   // the one-board-per-block form (two blocks per CU, 29 % more MFMAs) on the full batch: does a second resident block
         // fill the matrix pipe's idle phases, and what does the clock do then?
         float t = time_it([&] {
