@@ -92,6 +92,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch ships its own copy of the HIP runtime.  Whichever copy is mapped first serves the whole process, and a
+    # second, separately initialised one finds no device: torch's has to be the one, since the engine runs on torch's
+    # streams and memory.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise NnbError(
             f"{LIB_PATH} is missing: build it with `python -m alphazero_amd.build` "

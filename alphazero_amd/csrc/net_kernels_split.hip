@@ -108,160 +108,10 @@ __global__ void repack_conv0_split_kernel(const float *__restrict__ w, const flo
     split_half(w[i] * *scale, wh[i], wl[i]);
 }
 
-// ---------------------------------------------------------------------------
-// conv 128->128, 4x4, pad 2, + bias + ReLU (network.py:31-34), row-tile implicit GEMM with split
-// operands.  Same tiling as conv_rows_f16_kernel: an MFMA tile is ONE OUTPUT ROW of the block's NB
-// boards (cells board-major, NB*OW <= 32), so the (output row, kernel row) pairs that read only
-// padding are known at compile time and skipped; wave w owns output channels 32w..32w+31 for all
-// output rows.  The LDS image holds, per input pixel, one position of 528 bytes (hi halves, lo halves,
-// pad) with zero positions around every image row; a lane's fragment addresses are one base plus
-// compile-time offsets, the lo fragment 256 bytes behind the hi one.  One block per CU (the image of
-// three boards takes 145 KB), one wave per SIMD: fragments come through a register ring filled
-// ARING steps ahead, weights stream L2 -> registers BRING-1 k-steps ahead.
-//
-// FUSE_IN (first 128->128 layer): the input image is not read from memory but computed in place -
-// leaf encode (AlphaZeroAgent.preprocess, agent_code.py:76-89) and the 2->128 convolution
-// (network.py:29-30) from the side boards, with the layer's static output scale.
-// ---------------------------------------------------------------------------
 // The hi or lo weights of one 128->128 layer (16 taps x 8 k-steps x 4 KB) as a buffer resource: a fragment load is
 // then one instruction with a per-lane 32-bit offset and a scalar offset, and a read past the end returns zeros.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t conv_weight_rsrc(const u32x4 *w) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(w), 0, 128 * 128 * 16 * 2, 0x00027000);
-}
-
-// All four taps of kernel row KH.  The code of a block should stay resident in the instruction cache (64 KB
-// shared by two CUs; straight-line code that misses it runs at ~20 cycles per instruction), so there is ONE
-// body per kernel row: the tap loop is a real loop, the fragment ring is refilled across taps under a uniform
-// predicate and primed again at the start of each kernel row.
-//
-// TROWS = output rows per MFMA tile.  1: a tile is one output row of all the block's boards, and the tiles whose
-// kernel row KH reads only padding are skipped.  3 (one board per block, small batches): a tile is three
-// consecutive output rows of the board, every tile takes every kernel row, and the image carries two rows of zero
-// positions above and below the board.  Either way an output sums the same non-zero products in the same order.
-template <int IH, int IW, int ARING, int BRING, int KH, int TROWS = 1, int NACC = IH + 1>
-__device__ __forceinline__ void conv_split_row(f32x16 (&acc)[NACC], u32x4 (&bh)[BRING], u32x4 (&bl)[BRING],
-                                               const unsigned char *smem, int lane_base,
-                                               const __amdgpu_buffer_rsrc_t &rwh, const __amdgpu_buffer_rsrc_t &rwl, int woff) {
-    constexpr int W2 = IW + 2, PB = SP_PB;
-    constexpr int T0 = TROWS == 1 ? rows_t0(KH) : 0;
-#ifdef NNB_ABL_SMALL_TILES                                           // (timing experiments only: fewer tiles than the output has)
-    constexpr int NT = TROWS == 1 ? rows_t1(IH, KH) - T0 : (IH == 7 ? NNB_ABL_SMALL_TILES / 10 : NNB_ABL_SMALL_TILES % 10), STEPS = 8 * NT;
-#else
-    constexpr int NT = TROWS == 1 ? rows_t1(IH, KH) - T0 : (IH + TROWS) / TROWS, STEPS = 8 * NT;
-#endif
-    constexpr int TS = TROWS * W2 * PB;                          // bytes between consecutive tiles in the image
-    static_assert(T0 + NT <= NACC, "one accumulator per tile");
-    static_assert(STEPS % ARING == 0, "ring depth must divide the fragment pairs per tap");
-    u32x4 ahi[ARING], alo[ARING];
-    {
-        const unsigned char *p0 = smem + lane_base + ((KH - 2) * W2 - 2) * PB;
-#pragma unroll
-        for (int f = 0; f < ARING; ++f) {
-            const unsigned char *p = p0 + (T0 + f % NT) * TS + (f / NT) * 32;
-            ahi[f] = *reinterpret_cast<const u32x4 *>(p);
-            alo[f] = *reinterpret_cast<const u32x4 *>(p + SP_LO);
-        }
-    }
-#pragma unroll 1
-    for (int kw = 0; kw < 4; ++kw) {
-        const unsigned char *pv = smem + lane_base + ((KH - 2) * W2 + kw - 2) * PB;
-        const bool more = kw < 3;                                // uniform: another tap of this kernel row follows
-        const int step0 = (KH * 4 + kw) * 8;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-#ifndef NNB_ABL_NO_CONV_WEIGHT_LOADS                              // (timing experiments only: tools/split_bench.hip)
-            {                                                    // weights BRING-1 k-steps ahead: buffer loads with a scalar
-                const int nxt = step0 + ks + BRING - 1;            // offset per k-step (no 64-bit address arithmetic per lane);
-                bh[(ks + BRING - 1) & (BRING - 1)] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, nxt * 4096, 0);   // past the last
-                bl[(ks + BRING - 1) & (BRING - 1)] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, nxt * 4096, 0);   // k-step: zeros, unused
-            }
-#endif
-            const half8 wh = as_half8(bh[ks & (BRING - 1)]), wl = as_half8(bl[ks & (BRING - 1)]);
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int f = ks * NT + i, g = f + ARING;
-                const half8 xh = as_half8(ahi[f % ARING]), xl = as_half8(alo[f % ARING]);
-                acc[T0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, acc[T0 + i], 0, 0, 0);
-                acc[T0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, acc[T0 + i], 0, 0, 0);
-                acc[T0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, acc[T0 + i], 0, 0, 0);
-                if (g < STEPS) {
-                    const unsigned char *p = pv + (T0 + g % NT) * TS + (g / NT) * 32;
-                    ahi[g % ARING] = *reinterpret_cast<const u32x4 *>(p);
-                    alo[g % ARING] = *reinterpret_cast<const u32x4 *>(p + SP_LO);
-                } else if (more) {                               // first fragments of the next tap
-                    const int gg = g - STEPS;
-                    const unsigned char *p = pv + PB + (T0 + gg % NT) * TS + (gg / NT) * 32;
-                    ahi[g % ARING] = *reinterpret_cast<const u32x4 *>(p);
-                    alo[g % ARING] = *reinterpret_cast<const u32x4 *>(p + SP_LO);
-                }
-                __builtin_amdgcn_sched_barrier(0);               // keep the MFMA / LDS-read interleave as written
-            }
-        }
-    }
-}
-
-// Epilogue pieces.  A lane holds one output channel of 16 cells per row tile; which cells depends on the
-// lane half h only, so every per-cell constant is a select between two compile-time values.
-// Step 1: v = ReLU(acc * k[board] + bias) in place, and this lane's maximum per board.
-template <int IH, int IW, int NB>
-__device__ __forceinline__ void conv_split_finish(f32x16 (&acc)[IH + 1], const float (&kin)[NB], float bv,
-                                                  float (&bmax)[NB], int h) {
-    constexpr int OH = IH + 1, OW = IW + 1, RC = NB * OW;
-    static_for<16>([&](auto Rr) __attribute__((always_inline)) {
-        constexpr int r = decltype(Rr)::value;
-        constexpr int c0 = sigma((r & 3) + 8 * (r >> 2)), c1 = sigma((r & 3) + 8 * (r >> 2) + 4);
-        constexpr int j0 = c0 < RC ? c0 / OW : NB - 1, j1 = c1 < RC ? c1 / OW : NB - 1;
-        const bool live = h ? c1 < RC : c0 < RC;
-        const float k = h ? kin[j1] : kin[j0];
-        float mx = 0.f;
-        static_for<OH>([&](auto T) __attribute__((always_inline)) {
-            constexpr int t = decltype(T)::value;
-            const float v = fmaxf(__builtin_fmaf(acc[t][r], k, bv), 0.f);
-            acc[t][r] = v;
-            mx = fmaxf(mx, v);
-        });
-        mx = live ? mx : 0.f;
-        static_for<NB>([&](auto J) __attribute__((always_inline)) {
-            constexpr int j = decltype(J)::value;
-            if constexpr (j == j0 || j == j1) bmax[j] = fmaxf(bmax[j], (h ? j1 : j0) == j ? mx : 0.f);
-        });
-    });
-}
-
-// Step 2: quantise with the board's scale and put hi / lo into LDS: output cell (board j, row t, column c)
-// goes to position LEADO + j*BSO + t*RSO + c.  (BSO, RSO, LEADO) = (cells per board, cells per row, 0) is the
-// dense output tile that is copied to memory; (conv_board_stride, OW + 2, 2) is the input image of the next
-// 4x4 layer.  A lane swaps its (hi, lo) pair with the neighbouring channel's lane (same cell) so that the
-// even lane stores both hi halves and the odd lane both lo halves as one 32-bit word each.
-template <int IH, int IW, int NB, int BSO = (IH + 1) * (IW + 1), int RSO = IW + 1, int LEADO = 0>
-__device__ __forceinline__ void conv_split_store(const f32x16 (&acc)[IH + 1], const float (&sout)[NB],
-                                                 unsigned *ldsw, int ch, int odd, int h) {
-    constexpr int OH = IH + 1, OW = IW + 1, RC = NB * OW;
-    const int col = (ch >> 1) + (odd ? SP_LO / 4 : 0);           // dword inside a position
-    const unsigned psel = odd ? 0x03020706u : 0x05040100u;       // v_perm_b32 byte selector, bytes 4-7 = first operand
-    static_for<16>([&](auto Rr) __attribute__((always_inline)) {
-        constexpr int r = decltype(Rr)::value;
-        constexpr int c0 = sigma((r & 3) + 8 * (r >> 2)), c1 = sigma((r & 3) + 8 * (r >> 2) + 4);
-        constexpr int j0 = c0 < RC ? c0 / OW : NB - 1, j1 = c1 < RC ? c1 / OW : NB - 1;
-        constexpr int R0 = LEADO + j0 * BSO + c0 % OW, R1 = LEADO + j1 * BSO + c1 % OW;   // position of output row 0
-        const bool live = h ? c1 < RC : c0 < RC;
-        const float sc_out = h ? sout[j1] : sout[j0];
-        unsigned *dst = ldsw + (h ? R1 : R0) * (SP_PB / 4) + col;
-        if (live) {
-            static_for<OH>([&](auto T) __attribute__((always_inline)) {
-                constexpr int t = decltype(T)::value;
-                typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-                half2v pr;
-                const float x = acc[t][r] * sc_out;
-                pr[0] = (_Float16)x;
-                pr[1] = (_Float16)(x - (float)pr[0]);
-                const unsigned own = __builtin_bit_cast(unsigned, pr);
-                const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);   // lane ^ 1
-                // even lane: (own hi, other hi); odd lane: (other lo, own lo)
-                dst[t * RSO * (SP_PB / 4)] = __builtin_amdgcn_perm(other, own, psel);
-            });
-        }
-    });
 }
 
 #ifdef NNB_SPLIT_BENCH_CLOCKS
@@ -275,753 +125,25 @@ __device__ unsigned long long g_sp_clk[8];
 #define NNB_SP_WALL(i)
 #endif
 
-constexpr size_t conv_split_lds_bytes(int ih, int iw, int nb) {
-    int npos = 2 + nb * conv_board_stride(ih, iw) + 2, m = nb * (ih + 1) * (iw + 1);
-    return (size_t)(npos > m ? npos : m) * SP_PB + 256;         // + the per-wave board maxima
-}
-
-template <int IH, int IW, int NB, int BRING, int ARING, bool FUSE_IN>
-__global__ __launch_bounds__(256, 1) void conv_rows_split_kernel(const u32x4 *__restrict__ in,
-                                                                 const float *__restrict__ in_inv_scale,
-                                                                 const u32x4 *__restrict__ wph,
-                                                                 const u32x4 *__restrict__ wpl,
-                                                                 const float *__restrict__ bias,
-                                                                 const SplitScales *__restrict__ sc,
-                                                                 u32x4 *__restrict__ out,
-                                                                 float *__restrict__ out_inv_scale,
-                                                                 const int32_t *__restrict__ count_ptr, int n_fixed,
-                                                                 const u64 *__restrict__ side,
-                                                                 const u32x4 *__restrict__ w0h,
-                                                                 const u32x4 *__restrict__ w0l,
-                                                                 const float *__restrict__ b0) {
-    constexpr int OH = IH + 1, OW = IW + 1, IP = IH * IW, OP = OH * OW, W2 = IW + 2;
-    constexpr int RC = NB * OW;
-    static_assert(RC <= 32, "one output row of all boards must fit one 32-row MFMA tile");
-    constexpr int BS = conv_board_stride(IH, IW), LEAD = 2;
-    constexpr int NPOS = LEAD + NB * BS + 2;
-    constexpr int PB = SP_PB;
-    constexpr int REGION = (NPOS > NB * OP ? NPOS : NB * OP) * PB;   // image, later the output tile
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u32x4 *lds = reinterpret_cast<u32x4 *>(smem_raw);
-    float *s_max = reinterpret_cast<float *>(smem_raw + REGION);     // [4 waves][NB]
-
-    const int count = batch_count_sp(count_ptr, n_fixed);
-    const int b0i = blockIdx.x * NB;
-    if (b0i >= count) return;
-    const int nb_valid = min(NB, count - b0i);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, nt = tid >> 6, m = lane & 31, h = lane >> 5;
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    NNB_SP_STAMP(0) NNB_SP_WALL(5)
-
-    float kin[NB];                                               // 1 / (input scale * weight scale) per board
-    if constexpr (FUSE_IN) {
-        static_assert(IH == 7 && IW == 8, "the fused input layer produces 7x8 maps");
-        for (int e = tid; e < NPOS * SP_RS; e += 256) lds[e] = zero4;
-        __syncthreads();
-        // k = plane*16 + kh*4 + kw; lane half h holds k%16 in [8h, 8h+8)
-        half8 bwh[2], bwl[2];
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            bwh[pl] = as_half8(w0h[(nt * 32 + m) * 4 + 2 * pl + h]);
-            bwl[pl] = as_half8(w0l[(nt * 32 + m) * 4 + 2 * pl + h]);
-        }
-        const float bv_in = b0[nt * 32 + m];
-        const float inv_sw0 = sc->inv_sw0, sa1 = sc->sa1;
-        _Float16 *ldsh_in = reinterpret_cast<_Float16 *>(smem_raw);
-        for (int j = 0; j < nb_valid; ++j) {
-            const u64 planes[2] = {side[2 * (b0i + j)], side[2 * (b0i + j) + 1]};
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int pos = mt * 32 + m, oh = pos >> 3, ow = pos & 7;      // output cell of this MFMA row
-                f32x16 c;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) c[r] = 0.f;
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-                    half8 a;
-#pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {
-                        const int ih = oh + 2 * h + rr - 2;                    // kh = 2h + rr
-                        // bits iw = 0..6 of reference row ih: stones at bit iw*7 + (5 - ih)
-                        u64 t = (unsigned)ih < 6u ? (planes[pl] >> (5 - ih)) & c4::kBottomMask : 0;
-                        unsigned row = (unsigned)((t * 0x41041041040ULL) >> 42) & 0x7F;
-                        unsigned nib = ((row << 2) >> ow) & 0xF;               // bit kw <-> iw = ow + kw - 2
-#pragma unroll
-                        for (int kw = 0; kw < 4; ++kw) a[rr * 4 + kw] = ((nib >> kw) & 1) ? (_Float16)1.0f : (_Float16)0.0f;
-                    }
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bwl[pl], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bwh[pl], c, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int p = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (p < IP) {
-                        const float v = fmaxf(__builtin_fmaf(c[r], inv_sw0, bv_in), 0.f);
-                        _Float16 hi, lo;
-                        split_half(v * sa1, hi, lo);
-                        _Float16 *dst = ldsh_in + (LEAD + j * BS + (p / IW) * W2 + p % IW) * (PB / 2) + nt * 32 + m;
-                        dst[0] = hi;
-                        dst[128] = lo;
-                    }
-                }
-            }
-        }
-        const float k = sc->inv_sa1 * sc->inv_sw2;
-        static_for<NB>([&](auto J) __attribute__((always_inline)) { kin[decltype(J)::value] = k; });
-    } else {
-        // input pixels from memory in batches of SB loads per thread (one wave per SIMD: nothing else hides
-        // the latency of a load that is waited for at once), zeros into every position that holds no pixel
-        const u32x4 *src = in + (size_t)b0i * IP * 32;
-        constexpr int NDATA = NB * IP * 32, SB = 9, NBATCH = (NDATA + 256 * SB - 1) / (256 * SB);
-        const int ndata = nb_valid * IP * 32;
-        auto image_chunk = [&](int e) __attribute__((always_inline)) {      // data chunk e -> chunk index in the image
-            const int pix = e >> 5, q = e & 31, j = pix / IP, p = pix - j * IP;
-            return (LEAD + j * BS + (p / IW) * W2 + p % IW) * SP_RS + q;
-        };
-        u32x4 sv[SB];
-        static_for<SB>([&](auto K) __attribute__((always_inline)) {
-            constexpr int k = decltype(K)::value;
-            const int e = tid + 256 * k;
-            sv[k] = e < ndata ? src[e] : zero4;
-        });
-        for (int e = tid; e < NPOS * 32; e += 256) {             // zero positions, while the first batch is in flight
-            const int pos = e >> 5, q = e & 31;
-            const int rel = pos - LEAD, j = rel / BS, rem = rel - j * BS, ih = rem / W2, iw = rem - ih * W2;
-            const bool data = rel >= 0 && j < NB && ih < IH && iw < IW;
-            if (!data) lds[pos * SP_RS + q] = zero4;
-        }
-#pragma unroll 1
-        for (int bt = 0; bt < NBATCH; ++bt) {
-            static_for<SB>([&](auto K) __attribute__((always_inline)) {
-                constexpr int k = decltype(K)::value;
-                const int e = tid + 256 * (bt * SB + k);
-                if (e < NDATA) lds[image_chunk(e)] = sv[k];
-            });
-            if (bt + 1 < NBATCH)
-                static_for<SB>([&](auto K) __attribute__((always_inline)) {
-                    constexpr int k = decltype(K)::value;
-                    const int e = tid + 256 * ((bt + 1) * SB + k);
-                    sv[k] = e < ndata ? src[e] : zero4;
-                });
-        }
-        const float inv_sw = sc->inv_sw4;
-        static_for<NB>([&](auto J) __attribute__((always_inline)) {
-            constexpr int j = decltype(J)::value;
-            kin[j] = (j < nb_valid ? in_inv_scale[b0i + j] : 1.0f) * inv_sw;
-        });
-    }
-    __syncthreads();
-    NNB_SP_STAMP(1)
-
-    // this lane's cell of every output row: board j, column ow (lanes past the last cell repeat it)
-    int cell = sigma(m);
-    cell = cell < RC ? cell : RC - 1;
-    const int lane_base = (LEAD + (cell / OW) * BS + cell % OW) * PB + h * 16;
-
-    f32x16 acc[OH];
-#pragma unroll
-    for (int t = 0; t < OH; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    const __amdgpu_buffer_rsrc_t rwh = conv_weight_rsrc(wph), rwl = conv_weight_rsrc(wpl);
-    const int woff = (h * 128 + nt * 32 + m) * 16;
-    u32x4 bh[BRING], bl[BRING];
-#pragma unroll
-    for (int i = 0; i < BRING - 1; ++i) {
-        bh[i] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, i * 4096, 0);
-        bl[i] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, i * 4096, 0);
-    }
-    conv_split_row<IH, IW, ARING, BRING, 0>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-    conv_split_row<IH, IW, ARING, BRING, 1>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-    conv_split_row<IH, IW, ARING, BRING, 2>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-    conv_split_row<IH, IW, ARING, BRING, 3>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-
-    NNB_SP_STAMP(2)
-    // epilogue: bias + ReLU in float32, each board's maximum over the whole block, then hi / lo with
-    // that board's scale into the output tile [board][cell][hi 128 | lo 128] in LDS, then row-contiguous stores
-    const float bv = bias[nt * 32 + m];
-    float bmax[NB];
-    static_for<NB>([&](auto J) __attribute__((always_inline)) { bmax[decltype(J)::value] = 0.f; });
-    conv_split_finish<IH, IW, NB>(acc, kin, bv, bmax, h);
-    static_for<NB>([&](auto J) __attribute__((always_inline)) {
-        constexpr int j = decltype(J)::value;
-        float v = bmax[j];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-        if (lane == 0) s_max[nt * NB + j] = v;
-    });
-    __syncthreads();                                             // every wave is done with the image
-    NNB_SP_STAMP(4)
-    float sout[NB], sinv[NB];
-    static_for<NB>([&](auto J) __attribute__((always_inline)) {
-        constexpr int j = decltype(J)::value;
-        const float mx = fmaxf(fmaxf(s_max[j], s_max[NB + j]), fmaxf(s_max[2 * NB + j], s_max[3 * NB + j]));
-        sout[j] = pow2_scale(mx, sinv[j]);
-    });
-    {
-        unsigned *ldsw = reinterpret_cast<unsigned *>(smem_raw);
-        conv_split_store<IH, IW, NB>(acc, sout, ldsw, nt * 32 + m, m & 1, h);
-    }
-    __syncthreads();
-    NNB_SP_STAMP(7)
-    u32x4 *dst = out + (size_t)b0i * OP * 32;
-    const int nchunks = nb_valid * OP * 32;
-    constexpr int CB = 8;                                        // LDS reads in flight per thread
-    for (int e0 = tid; e0 < nchunks; e0 += 256 * CB) {
-        u32x4 cv[CB];
-        static_for<CB>([&](auto K) __attribute__((always_inline)) {
-            constexpr int k = decltype(K)::value;
-            const int e = min(e0 + 256 * k, nchunks - 1);
-            cv[k] = lds[(e >> 5) * SP_RS + (e & 31)];
-        });
-        static_for<CB>([&](auto K) __attribute__((always_inline)) {
-            constexpr int k = decltype(K)::value;
-            const int e = e0 + 256 * k;
-            if (e < nchunks) dst[e] = cv[k];
-        });
-    }
-    float my_inv = sinv[0];                                      // selects, not an indexed read of the array
-    static_for<NB>([&](auto J) __attribute__((always_inline)) {
-        constexpr int j = decltype(J)::value;
-        my_inv = tid == j ? sinv[j] : my_inv;
-    });
-    if (tid < nb_valid) out_inv_scale[b0i + tid] = my_inv;
-    NNB_SP_STAMP(3) NNB_SP_WALL(6)
-}
-
-// ---------------------------------------------------------------------------
-// Both 128->128 layers in one launch (network.py:29-34 from the side boards to the second ReLU): the block
-// runs the first layer as conv_rows_split_kernel<7, 8, NB, .., true> does, but its epilogue writes the
-// quantised output straight into the LDS image the second layer reads (same hi / lo halves and per-board
-// scales as the two-launch form, so the results are the same bit for bit), and the second layer follows in
-// the same block.  The 7x8 -> 8x9 activations never exist in memory (147 MB written and read back per 4096
-// leaves otherwise), and the second layer's staging loop and the first layer's copy-out disappear.
-// WRITE_MID also copies those activations out (act2, act2_inv) for callers that want to look at them.
-// ---------------------------------------------------------------------------
-constexpr size_t conv_pair_lds_bytes(int nb) {
-    size_t a = conv_split_lds_bytes(7, 8, nb), b = conv_split_lds_bytes(8, 9, nb);
-    return a > b ? a : b;
-}
-
-template <int NB, int BRING, int ARING, bool WRITE_MID>
-__global__ __launch_bounds__(256, 1) void conv_pair_split_kernel(const u64 *__restrict__ side,
-                                                                 const u32x4 *__restrict__ w0h,
-                                                                 const u32x4 *__restrict__ w0l,
-                                                                 const float *__restrict__ b0,
-                                                                 const u32x4 *__restrict__ w2h,
-                                                                 const u32x4 *__restrict__ w2l,
-                                                                 const float *__restrict__ bias2,
-                                                                 const u32x4 *__restrict__ w4h,
-                                                                 const u32x4 *__restrict__ w4l,
-                                                                 const float *__restrict__ bias4,
-                                                                 const SplitScales *__restrict__ sc,
-                                                                 u32x4 *__restrict__ mid, float *__restrict__ mid_inv_scale,
-                                                                 u32x4 *__restrict__ out, float *__restrict__ out_inv_scale,
-                                                                 const int32_t *__restrict__ count_ptr, int n_fixed,
-                                                                 unsigned long long *__restrict__ clk) {
-    constexpr int PB = SP_PB, LEAD = 2;
-    // clk != null (profiling): block 0 stamps the shader-cycle counter and the 100 MHz wall clock at its start and
-    // end, from which the host reads the shader clock this kernel ran at
-    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter(); clk[1] = wall_clock64(); }
-    // first layer: 7x8 -> 8x9; second: 8x9 -> 9x10
-    constexpr int IH1 = 7, IW1 = 8, IP1 = IH1 * IW1, W21 = IW1 + 2, BS1 = conv_board_stride(IH1, IW1), NPOS1 = LEAD + NB * BS1 + 2;
-    constexpr int IH2 = 8, IW2 = 9, IP2 = IH2 * IW2, W22 = IW2 + 2, BS2 = conv_board_stride(IH2, IW2), NPOS2 = LEAD + NB * BS2 + 2;
-    constexpr int OH2 = IH2 + 1, OW2 = IW2 + 1, OP2 = OH2 * OW2;
-    static_assert(NB * OW2 <= 32, "one output row of all boards must fit one 32-row MFMA tile");
-    constexpr int R1 = (NPOS1 > NB * IP2 ? NPOS1 : NB * IP2), R2 = (NPOS2 > NB * OP2 ? NPOS2 : NB * OP2);
-    constexpr int REGION = (R1 > R2 ? R1 : R2) * PB;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u32x4 *lds = reinterpret_cast<u32x4 *>(smem_raw);
-    float *s_max = reinterpret_cast<float *>(smem_raw + REGION);     // [4 waves][NB]
-
-    const int count = batch_count_sp(count_ptr, n_fixed);
-    const int b0i = blockIdx.x * NB;
-    if (b0i >= count) return;
-    const int nb_valid = min(NB, count - b0i);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, nt = tid >> 6, m = lane & 31, h = lane >> 5;
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    NNB_SP_STAMP(0) NNB_SP_WALL(5)
-
-    // ---- leaf encode + 2->128 layer into the first image (as conv_rows_split_kernel<.., true>) ----
-    // zeros wherever the 2->128 layer below writes no pixel: the padding positions (enumerated as for the second
-    // image further down), and everything when boards are missing from the block
-    constexpr int PADB1 = 2 * IH1 + (BS1 - IH1 * W21), NPAD1 = LEAD + NB * PADB1 + 2;
-    static_assert(NPAD1 + NB * IP1 == NPOS1, "every position of the image is a pixel or padding");
-    if (nb_valid < NB) {
-        for (int e = tid; e < NPOS1 * SP_RS; e += 256) lds[e] = zero4;
-        __syncthreads();
-    } else {
-        for (int e = tid; e < NPAD1 * 32; e += 256) {
-            const int k = e >> 5, q = e & 31;
-            int pos;
-            if (k < LEAD) pos = k;
-            else if (k >= LEAD + NB * PADB1) pos = LEAD + NB * BS1 + (k - LEAD - NB * PADB1);
-            else {
-                const int kk = k - LEAD, j = kk / PADB1, r = kk - j * PADB1;
-                pos = LEAD + j * BS1 + (r < 2 * IH1 ? (r >> 1) * W21 + IW1 + (r & 1) : IH1 * W21 + (r - 2 * IH1));
-            }
-            lds[pos * SP_RS + q] = zero4;
-        }
-    }
-    {
-        half8 bwh[2], bwl[2];
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            bwh[pl] = as_half8(w0h[(nt * 32 + m) * 4 + 2 * pl + h]);
-            bwl[pl] = as_half8(w0l[(nt * 32 + m) * 4 + 2 * pl + h]);
-        }
-        const float bv_in = b0[nt * 32 + m];
-        const float inv_sw0 = sc->inv_sw0, sa1 = sc->sa1;
-        _Float16 *ldsh_in = reinterpret_cast<_Float16 *>(smem_raw);
-        for (int j = 0; j < nb_valid; ++j) {
-            const u64 planes[2] = {side[2 * (b0i + j)], side[2 * (b0i + j) + 1]};
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int pos = mt * 32 + m, oh = pos >> 3, ow = pos & 7;
-                f32x16 c;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) c[r] = 0.f;
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-                    half8 a;
-#pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {
-                        const int ih = oh + 2 * h + rr - 2;
-                        u64 t = (unsigned)ih < 6u ? (planes[pl] >> (5 - ih)) & c4::kBottomMask : 0;
-                        unsigned row = (unsigned)((t * 0x41041041040ULL) >> 42) & 0x7F;
-                        unsigned nib = ((row << 2) >> ow) & 0xF;
-#pragma unroll
-                        for (int kw = 0; kw < 4; ++kw) a[rr * 4 + kw] = ((nib >> kw) & 1) ? (_Float16)1.0f : (_Float16)0.0f;
-                    }
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bwl[pl], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bwh[pl], c, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int p = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (p < IP1) {
-                        const float v = fmaxf(__builtin_fmaf(c[r], inv_sw0, bv_in), 0.f);
-                        _Float16 hi, lo;
-                        split_half(v * sa1, hi, lo);
-                        _Float16 *dst = ldsh_in + (LEAD + j * BS1 + (p / IW1) * W21 + p % IW1) * (PB / 2) + nt * 32 + m;
-                        dst[0] = hi;
-                        dst[128] = lo;
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    NNB_SP_STAMP(1)
-
-    u32x4 bh[BRING], bl[BRING];
-    const int woff = (h * 128 + nt * 32 + m) * 16;              // this lane's weight fragment inside a k-step's 4 KB
-    float kin2[NB];                                              // 1 / (scale of the middle activations * weight scale)
-    // ---- first 128->128 layer ----
-    {
-        float kin[NB];
-        const float k = sc->inv_sa1 * sc->inv_sw2;
-        static_for<NB>([&](auto J) __attribute__((always_inline)) { kin[decltype(J)::value] = k; });
-        constexpr int OW = IW1 + 1, RC = NB * OW;
-        int cell = sigma(m);
-        cell = cell < RC ? cell : RC - 1;
-        const int lane_base = (LEAD + (cell / OW) * BS1 + cell % OW) * PB + h * 16;
-        f32x16 acc[IH1 + 1];
-#pragma unroll
-        for (int t = 0; t < IH1 + 1; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        const __amdgpu_buffer_rsrc_t rwh = conv_weight_rsrc(w2h), rwl = conv_weight_rsrc(w2l);
-#pragma unroll
-        for (int i = 0; i < BRING - 1; ++i) {
-            bh[i] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, i * 4096, 0);
-            bl[i] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, i * 4096, 0);
-        }
-        conv_split_row<IH1, IW1, ARING, BRING, 0>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-        conv_split_row<IH1, IW1, ARING, BRING, 1>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-        conv_split_row<IH1, IW1, ARING, BRING, 2>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-        conv_split_row<IH1, IW1, ARING, BRING, 3>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-        NNB_SP_STAMP(2)
-
-        const float bv = bias2[nt * 32 + m];
-        float bmax[NB];
-        static_for<NB>([&](auto J) __attribute__((always_inline)) { bmax[decltype(J)::value] = 0.f; });
-        conv_split_finish<IH1, IW1, NB>(acc, kin, bv, bmax, h);
-        static_for<NB>([&](auto J) __attribute__((always_inline)) {
-            constexpr int j = decltype(J)::value;
-            float v = bmax[j];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-            if (lane == 0) s_max[nt * NB + j] = v;
-        });
-        __syncthreads();                                         // every wave is done with the first image
-        float sout[NB], sinv[NB];
-        static_for<NB>([&](auto J) __attribute__((always_inline)) {
-            constexpr int j = decltype(J)::value;
-            const float mx = fmaxf(fmaxf(s_max[j], s_max[NB + j]), fmaxf(s_max[2 * NB + j], s_max[3 * NB + j]));
-            sout[j] = pow2_scale(mx, sinv[j]);
-        });
-        // the second image: zeros wherever there is no pixel, the quantised activations where there is one
-        // (the positions that hold no pixel, enumerated: LEAD in front, per board two behind each image row and the
-        // BS2 - IH2*W22 that pad the board stride, two behind the last board)
-        constexpr int PADB = 2 * IH2 + (BS2 - IH2 * W22), NPAD = LEAD + NB * PADB + 2;
-        static_assert(NPAD + NB * IP2 == NPOS2, "every position of the image is a pixel or padding");
-        for (int e = tid; e < NPAD * 32; e += 256) {
-            const int k = e >> 5, q = e & 31;
-            int pos;
-            if (k < LEAD) pos = k;
-            else if (k >= LEAD + NB * PADB) pos = LEAD + NB * BS2 + (k - LEAD - NB * PADB);
-            else {
-                const int kk = k - LEAD, j = kk / PADB, r = kk - j * PADB;
-                pos = LEAD + j * BS2 + (r < 2 * IH2 ? (r >> 1) * W22 + IW2 + (r & 1) : IH2 * W22 + (r - 2 * IH2));
-            }
-            lds[pos * SP_RS + q] = zero4;
-        }
-        conv_split_store<IH1, IW1, NB, BS2, W22, LEAD>(acc, sout, reinterpret_cast<unsigned *>(smem_raw), nt * 32 + m, m & 1, h);
-        const float inv_sw4 = sc->inv_sw4;
-        static_for<NB>([&](auto J) __attribute__((always_inline)) {
-            constexpr int j = decltype(J)::value;
-            kin2[j] = sinv[j] * inv_sw4;
-        });
-        if constexpr (WRITE_MID) {
-            float my_inv = sinv[0];
-            static_for<NB>([&](auto J) __attribute__((always_inline)) {
-                constexpr int j = decltype(J)::value;
-                my_inv = tid == j ? sinv[j] : my_inv;
-            });
-            if (tid < nb_valid) mid_inv_scale[b0i + tid] = my_inv;
-        }
-        __syncthreads();                                         // the second image is complete (s_max may be reused)
-        if constexpr (WRITE_MID) {
-            u32x4 *dst = mid + (size_t)b0i * IP2 * 32;
-            const int nchunks = nb_valid * IP2 * 32;
-            for (int e = tid; e < nchunks; e += 256) {
-                const int pix = e >> 5, q = e & 31, j = pix / IP2, p = pix - j * IP2;
-                dst[e] = lds[(LEAD + j * BS2 + (p / IW2) * W22 + p % IW2) * SP_RS + q];
-            }
-        }
-    }
-
-    NNB_SP_STAMP(4)
-    // ---- second 128->128 layer ----
-    constexpr int OW = OW2, RC = NB * OW;
-    int cell = sigma(m);
-    cell = cell < RC ? cell : RC - 1;
-    const int lane_base = (LEAD + (cell / OW) * BS2 + cell % OW) * PB + h * 16;
-    f32x16 acc[OH2];
-#pragma unroll
-    for (int t = 0; t < OH2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const __amdgpu_buffer_rsrc_t rwh = conv_weight_rsrc(w4h), rwl = conv_weight_rsrc(w4l);
-#pragma unroll
-    for (int i = 0; i < BRING - 1; ++i) {
-        bh[i] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, i * 4096, 0);
-        bl[i] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, i * 4096, 0);
-    }
-    conv_split_row<IH2, IW2, ARING, BRING, 0>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-    conv_split_row<IH2, IW2, ARING, BRING, 1>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-    conv_split_row<IH2, IW2, ARING, BRING, 2>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-    conv_split_row<IH2, IW2, ARING, BRING, 3>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-    NNB_SP_STAMP(7)
-
-    const float bv = bias4[nt * 32 + m];
-    float bmax[NB];
-    static_for<NB>([&](auto J) __attribute__((always_inline)) { bmax[decltype(J)::value] = 0.f; });
-    conv_split_finish<IH2, IW2, NB>(acc, kin2, bv, bmax, h);
-    static_for<NB>([&](auto J) __attribute__((always_inline)) {
-        constexpr int j = decltype(J)::value;
-        float v = bmax[j];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-        if (lane == 0) s_max[nt * NB + j] = v;
-    });
-    __syncthreads();                                             // every wave is done with the second image
-    float sout[NB], sinv[NB];
-    static_for<NB>([&](auto J) __attribute__((always_inline)) {
-        constexpr int j = decltype(J)::value;
-        const float mx = fmaxf(fmaxf(s_max[j], s_max[NB + j]), fmaxf(s_max[2 * NB + j], s_max[3 * NB + j]));
-        sout[j] = pow2_scale(mx, sinv[j]);
-    });
-    conv_split_store<IH2, IW2, NB>(acc, sout, reinterpret_cast<unsigned *>(smem_raw), nt * 32 + m, m & 1, h);
-    __syncthreads();
-    u32x4 *dst = out + (size_t)b0i * OP2 * 32;
-    const int nchunks = nb_valid * OP2 * 32;
-    constexpr int CB = 8;                                        // LDS reads in flight per thread
-    for (int e0 = tid; e0 < nchunks; e0 += 256 * CB) {
-        u32x4 cv[CB];
-        static_for<CB>([&](auto K) __attribute__((always_inline)) {
-            constexpr int k = decltype(K)::value;
-            const int e = min(e0 + 256 * k, nchunks - 1);
-            cv[k] = lds[(e >> 5) * SP_RS + (e & 31)];
-        });
-        static_for<CB>([&](auto K) __attribute__((always_inline)) {
-            constexpr int k = decltype(K)::value;
-            const int e = e0 + 256 * k;
-            if (e < nchunks) dst[e] = cv[k];
-        });
-    }
-    float my_inv = sinv[0];
-    static_for<NB>([&](auto J) __attribute__((always_inline)) {
-        constexpr int j = decltype(J)::value;
-        my_inv = tid == j ? sinv[j] : my_inv;
-    });
-    if (tid < nb_valid) out_inv_scale[b0i + tid] = my_inv;
-    NNB_SP_STAMP(3) NNB_SP_WALL(6)
-    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[2] = __builtin_readcyclecounter(); clk[3] = wall_clock64(); }
-}
-
-// ---------------------------------------------------------------------------
-// conv_pair_split_kernel for small batches (single searches, small tournaments, the last games of a round): ONE
-// board per block, so a handful of boards spreads over as many CUs, and an MFMA tile is three consecutive output
-// rows of the board (27 or 30 of 32 cells) instead of one row of three boards - 3 tiles per layer where the
-// large-batch form issues 8 and 9.  Same halves, same per-board scales, same order of the non-zero products per
-// output: results equal conv_pair_split_kernel's bit for bit.
-// ---------------------------------------------------------------------------
-// Image of one board: two lead positions, 12 image rows of iw + 2 positions (two rows of zeros above the board, the
-// board's rows, zeros below: the three tiles cover output rows 0..8, whose last kernel row reads image row 9 + 2),
-// two tail positions.
-constexpr int conv_small_positions(int ih, int iw) { return 2 + (ih + 4 > 12 ? ih + 4 : 12) * (iw + 2) + 2; }
-constexpr size_t conv_pair_small_lds_bytes() {
-    int a = conv_small_positions(7, 8), b = conv_small_positions(8, 9), c = 9 * 10;
+// LDS image of one board's input to a 4x4 / pad 2 layer: per pixel one position of 528 bytes (128 hi halves, 128 lo
+// halves, pad), two lead positions, 12 image rows of iw + 2 positions (two rows of zeros above the board, the board's
+// rows with two zero positions behind each, zeros below), two tail positions.  Every tap of every output cell is then
+// an unconditional read: the lane's base position plus a compile-time offset, the lo fragment 256 bytes behind the hi.
+constexpr int conv_board_positions(int ih, int iw) { return 2 + (ih + 4 > 12 ? ih + 4 : 12) * (iw + 2) + 2; }
+constexpr size_t conv_board_lds_bytes() {
+    int a = conv_board_positions(7, 8), b = conv_board_positions(8, 9), c = 9 * 10;
     int m = a > b ? a : b;
-    return (size_t)(m > c ? m : c) * SP_PB + 64;
-}
-
-// this lane's maximum of ReLU(acc * k + bias) over its cells; a tile's cell c is row 3t + c / OW, column c % OW
-template <int OH, int OW, int NT>
-__device__ __forceinline__ float conv_small_max(const f32x16 (&acc)[NT], float k, float bv, int h) {
-    float mx = 0.f;
-    static_for<16>([&](auto Rr) __attribute__((always_inline)) {
-        constexpr int r = decltype(Rr)::value;
-        constexpr int c0 = sigma((r & 3) + 8 * (r >> 2)), c1 = sigma((r & 3) + 8 * (r >> 2) + 4);
-        static_for<NT>([&](auto T) __attribute__((always_inline)) {
-            constexpr int t = decltype(T)::value;
-            constexpr bool l0 = c0 < 3 * OW && 3 * t + c0 / OW < OH, l1 = c1 < 3 * OW && 3 * t + c1 / OW < OH;
-            const float v = fmaxf(__builtin_fmaf(acc[t][r], k, bv), 0.f);
-            mx = fmaxf(mx, (h ? l1 : l0) ? v : 0.f);
-        });
-    });
-    return mx;
-}
-
-// ReLU(acc * k + bias) quantised with the board's scale, hi / lo into LDS position LEADO + row * RSO + column
-// (the lane-pair packing of conv_split_store)
-template <int OH, int OW, int NT, int RSO, int LEADO>
-__device__ __forceinline__ void conv_small_store(const f32x16 (&acc)[NT], float k, float bv, float sc_out, unsigned *ldsw,
-                                                 int ch, int odd, int h) {
-    const int col = (ch >> 1) + (odd ? SP_LO / 4 : 0);
-    const unsigned psel = odd ? 0x03020706u : 0x05040100u;
-    static_for<16>([&](auto Rr) __attribute__((always_inline)) {
-        constexpr int r = decltype(Rr)::value;
-        constexpr int c0 = sigma((r & 3) + 8 * (r >> 2)), c1 = sigma((r & 3) + 8 * (r >> 2) + 4);
-        static_for<NT>([&](auto T) __attribute__((always_inline)) {
-            constexpr int t = decltype(T)::value;
-            constexpr bool l0 = c0 < 3 * OW && 3 * t + c0 / OW < OH, l1 = c1 < 3 * OW && 3 * t + c1 / OW < OH;
-            constexpr int P0 = l0 ? LEADO + (3 * t + c0 / OW) * RSO + c0 % OW : 0;
-            constexpr int P1 = l1 ? LEADO + (3 * t + c1 / OW) * RSO + c1 % OW : 0;
-            if (h ? l1 : l0) {
-                typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-                half2v pr;
-                const float x = fmaxf(__builtin_fmaf(acc[t][r], k, bv), 0.f) * sc_out;
-                pr[0] = (_Float16)x;
-                pr[1] = (_Float16)(x - (float)pr[0]);
-                const unsigned own = __builtin_bit_cast(unsigned, pr);
-                const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);   // lane ^ 1
-                ldsw[(h ? P1 : P0) * (SP_PB / 4) + col] = __builtin_amdgcn_perm(other, own, psel);
-            }
-        });
-    });
-}
-
-template <int BRING, int ARING, bool WRITE_MID>
-__global__ __launch_bounds__(256, 2) void conv_pair_split_small_kernel(const u64 *__restrict__ side,
-                                                                       const u32x4 *__restrict__ w0h,
-                                                                       const u32x4 *__restrict__ w0l,
-                                                                       const float *__restrict__ b0,
-                                                                       const u32x4 *__restrict__ w2h,
-                                                                       const u32x4 *__restrict__ w2l,
-                                                                       const float *__restrict__ bias2,
-                                                                       const u32x4 *__restrict__ w4h,
-                                                                       const u32x4 *__restrict__ w4l,
-                                                                       const float *__restrict__ bias4,
-                                                                       const SplitScales *__restrict__ sc,
-                                                                       u32x4 *__restrict__ mid, float *__restrict__ mid_inv_scale,
-                                                                       u32x4 *__restrict__ out, float *__restrict__ out_inv_scale,
-                                                                       const int32_t *__restrict__ count_ptr, int n_fixed) {
-    constexpr int PB = SP_PB;
-    constexpr int IH1 = 7, IW1 = 8, IP1 = IH1 * IW1, W21 = IW1 + 2, NPOS1 = conv_small_positions(IH1, IW1), LEAD1 = 2 + 2 * W21;
-    constexpr int IH2 = 8, IW2 = 9, IP2 = IH2 * IW2, W22 = IW2 + 2, NPOS2 = conv_small_positions(IH2, IW2), LEAD2 = 2 + 2 * W22;
-    constexpr int OH1 = IH1 + 1, OW1 = IW1 + 1, OH2 = IH2 + 1, OW2 = IW2 + 1, OP2 = OH2 * OW2;
-    constexpr int NT = 3;
-    static_assert((OH1 + 2) / 3 == NT && (OH2 + 2) / 3 == NT && 3 * OW2 <= 32, "three tiles of three rows per layer");
-    constexpr int REGION = (NPOS2 > NPOS1 ? (NPOS2 > OP2 ? NPOS2 : OP2) : (NPOS1 > OP2 ? NPOS1 : OP2)) * PB;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u32x4 *lds = reinterpret_cast<u32x4 *>(smem_raw);
-    float *s_max = reinterpret_cast<float *>(smem_raw + REGION);     // [4 waves]
-
-    const int count = batch_count_sp(count_ptr, n_fixed);
-    const int board = blockIdx.x;
-    if (board >= count) return;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, nt = tid >> 6, m = lane & 31, h = lane >> 5;
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
-    // ---- leaf encode + 2->128 layer into the first image ----
-    for (int e = tid; e < NPOS1 * SP_RS; e += 256) lds[e] = zero4;
-    __syncthreads();
-    {
-        half8 bwh[2], bwl[2];
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            bwh[pl] = as_half8(w0h[(nt * 32 + m) * 4 + 2 * pl + h]);
-            bwl[pl] = as_half8(w0l[(nt * 32 + m) * 4 + 2 * pl + h]);
-        }
-        const float bv_in = b0[nt * 32 + m];
-        const float inv_sw0 = sc->inv_sw0, sa1 = sc->sa1;
-        _Float16 *ldsh_in = reinterpret_cast<_Float16 *>(smem_raw);
-        const u64 planes[2] = {side[2 * board], side[2 * board + 1]};
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int pos = mt * 32 + m, oh = pos >> 3, ow = pos & 7;
-            f32x16 c;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) c[r] = 0.f;
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                half8 a;
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    const int ih = oh + 2 * h + rr - 2;
-                    u64 t = (unsigned)ih < 6u ? (planes[pl] >> (5 - ih)) & c4::kBottomMask : 0;
-                    unsigned row = (unsigned)((t * 0x41041041040ULL) >> 42) & 0x7F;
-                    unsigned nib = ((row << 2) >> ow) & 0xF;
-#pragma unroll
-                    for (int kw = 0; kw < 4; ++kw) a[rr * 4 + kw] = ((nib >> kw) & 1) ? (_Float16)1.0f : (_Float16)0.0f;
-                }
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bwl[pl], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bwh[pl], c, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int p = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (p < IP1) {
-                    const float v = fmaxf(__builtin_fmaf(c[r], inv_sw0, bv_in), 0.f);
-                    _Float16 hi, lo;
-                    split_half(v * sa1, hi, lo);
-                    _Float16 *dst = ldsh_in + (LEAD1 + (p / IW1) * W21 + p % IW1) * (PB / 2) + nt * 32 + m;
-                    dst[0] = hi;
-                    dst[128] = lo;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    u32x4 bh[BRING], bl[BRING];
-    const int woff = (h * 128 + nt * 32 + m) * 16;
-    const int ch = nt * 32 + m;
-    float k2;                                                    // 1 / (scale of the middle activations * weight scale)
-    // ---- first 128->128 layer ----
-    {
-        const float k1 = sc->inv_sa1 * sc->inv_sw2;
-        int cell = sigma(m);
-        cell = cell < 3 * OW1 ? cell : 3 * OW1 - 1;
-        const int lane_base = (LEAD1 + (cell / OW1) * W21 + cell % OW1) * PB + h * 16;
-        f32x16 acc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        const __amdgpu_buffer_rsrc_t rwh = conv_weight_rsrc(w2h), rwl = conv_weight_rsrc(w2l);
-#pragma unroll
-        for (int i = 0; i < BRING - 1; ++i) {
-            bh[i] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, i * 4096, 0);
-            bl[i] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, i * 4096, 0);
-        }
-        conv_split_row<IH1, IW1, ARING, BRING, 0, 3, NT>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-        conv_split_row<IH1, IW1, ARING, BRING, 1, 3, NT>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-        conv_split_row<IH1, IW1, ARING, BRING, 2, 3, NT>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-        conv_split_row<IH1, IW1, ARING, BRING, 3, 3, NT>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-
-        const float bv = bias2[ch];
-        float v = conv_small_max<OH1, OW1, NT>(acc, k1, bv, h);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-        if (lane == 0) s_max[nt] = v;
-        __syncthreads();                                         // every wave is done with the first image
-        float sinv;
-        const float sout = pow2_scale(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])), sinv);
-        // the second image: zeros wherever there is no pixel (two rows above, two positions behind every image row,
-        // two rows and the tail below), the quantised activations where there is one
-        constexpr int TOP = LEAD2, BOT = NPOS2 - (LEAD2 + IH2 * W22), NPAD = TOP + 2 * IH2 + BOT;
-        static_assert(NPAD + IP2 == NPOS2, "every position of the image is a pixel or padding");
-        for (int e = tid; e < NPAD * 32; e += 256) {
-            const int kk = e >> 5, q = e & 31;
-            const int pos = kk < TOP ? kk
-                          : kk < TOP + 2 * IH2 ? LEAD2 + ((kk - TOP) >> 1) * W22 + IW2 + ((kk - TOP) & 1)
-                                               : LEAD2 + IH2 * W22 + (kk - TOP - 2 * IH2);
-            lds[pos * SP_RS + q] = zero4;
-        }
-        conv_small_store<OH1, OW1, NT, W22, LEAD2>(acc, k1, bv, sout, reinterpret_cast<unsigned *>(smem_raw), ch, m & 1, h);
-        k2 = sinv * sc->inv_sw4;
-        if constexpr (WRITE_MID) {
-            if (tid == 0) mid_inv_scale[board] = sinv;
-        }
-        __syncthreads();                                         // the second image is complete (s_max may be reused)
-        if constexpr (WRITE_MID) {
-            u32x4 *dst = mid + (size_t)board * IP2 * 32;
-            for (int e = tid; e < IP2 * 32; e += 256) {
-                const int p = e >> 5, q = e & 31;
-                dst[e] = lds[(LEAD2 + (p / IW2) * W22 + p % IW2) * SP_RS + q];
-            }
-        }
-    }
-
-    // ---- second 128->128 layer ----
-    int cell = sigma(m);
-    cell = cell < 3 * OW2 ? cell : 3 * OW2 - 1;
-    const int lane_base = (LEAD2 + (cell / OW2) * W22 + cell % OW2) * PB + h * 16;
-    f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const __amdgpu_buffer_rsrc_t rwh = conv_weight_rsrc(w4h), rwl = conv_weight_rsrc(w4l);
-#pragma unroll
-    for (int i = 0; i < BRING - 1; ++i) {
-        bh[i] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, i * 4096, 0);
-        bl[i] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, i * 4096, 0);
-    }
-    conv_split_row<IH2, IW2, ARING, BRING, 0, 3, NT>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-    conv_split_row<IH2, IW2, ARING, BRING, 1, 3, NT>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-    conv_split_row<IH2, IW2, ARING, BRING, 2, 3, NT>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-    conv_split_row<IH2, IW2, ARING, BRING, 3, 3, NT>(acc, bh, bl, smem_raw, lane_base, rwh, rwl, woff);
-
-    const float bv = bias4[ch];
-    float v = conv_small_max<OH2, OW2, NT>(acc, k2, bv, h);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    if (lane == 0) s_max[nt] = v;
-    __syncthreads();                                             // every wave is done with the second image
-    float sinv;
-    const float sout = pow2_scale(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])), sinv);
-    conv_small_store<OH2, OW2, NT, OW2, 0>(acc, k2, bv, sout, reinterpret_cast<unsigned *>(smem_raw), ch, m & 1, h);
-    __syncthreads();
-    u32x4 *dst = out + (size_t)board * OP2 * 32;
-    for (int e = tid; e < OP2 * 32; e += 256) dst[e] = lds[(e >> 5) * SP_RS + (e & 31)];
-    if (tid == 0) out_inv_scale[board] = sinv;
+    return (size_t)(m > c ? m : c) * SP_PB + 64;                // + the per-wave board maxima
 }
 
 // ---------------------------------------------------------------------------
 // All three convolutions, ONE board per block, 16-cell tiles (conv_board_split_kernel).
 //
 // The board's output cells are taken row-major, 16 at a time, as the rows of v_mfma_f32_16x16x32_f16 tiles: 72 cells
-// = 5 tiles for the 7x8 -> 8x9 layer, 90 cells = 6 tiles for 8x9 -> 9x10 (the 3-boards-per-block form fills 27 and 30
-// of its 32 rows, and a 32-row tile of one board would waste a quarter of the last one).  A tile spans at most three
+// = 5 tiles for the 7x8 -> 8x9 layer, 90 cells = 6 tiles for 8x9 -> 9x10 (a 32-row tile of one board would waste a
+// quarter of the last one; one output row of three boards fills 27 and 30 of 32 rows, but three boards' images take
+// 145 KB of LDS: one block per CU, one wave per SIMD, nothing to run under the 18 % of a block's cycles that are not
+// matrix work - measured 724 us against 637 us per 3979 boards).  A tile spans at most three
 // output rows, so the (tile, kernel row) pairs that read nothing but padding are still known at compile time and
 // skipped.  The image of one board takes 72 KB of LDS and a wave at most 256 registers, so TWO blocks share a CU:
 // while one is in its prologue or one of its epilogues (no matrix work), the other one's waves keep the matrix pipe
@@ -1037,7 +159,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int IH, int IW>
 struct BoardGeom {
     static constexpr int OH = IH + 1, OW = IW + 1, NC = OH * OW, NT = (NC + 15) / 16, W2 = IW + 2, LEAD = 2 + 2 * W2;
-    static constexpr int NPOS = conv_small_positions(IH, IW);
+    static constexpr int NPOS = conv_board_positions(IH, IW);
     static constexpr int row_first(int t) { return (16 * t) / OW; }
     static constexpr int row_last(int t) { return (16 * t + 15 < NC ? 16 * t + 15 : NC - 1) / OW; }
     // kernel row kh of tile t reads at least one input row
@@ -1072,6 +194,7 @@ __device__ __forceinline__ void conv_board_row(f32x4 (&acc)[NT][2], u32x4 (&bh)[
             constexpr int cur = ks & 1, nxt = cur ^ 1;
             constexpr int slot = ks % BRING, fill = (ks + BRING - 1) % BRING;
             static_assert(4 % BRING == 0, "the weight ring must divide the k-steps of a tap");
+#ifndef NNB_ABL_NO_CONV_WEIGHT_LOADS                              // (timing experiments only: tools/split_bench.hip)
             {
                 const int sn = (step0 + ks + BRING - 1) * 8192;      // past the layer's last step: zeros, never used
                 bh[fill][0] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, sn, 0);
@@ -1079,6 +202,7 @@ __device__ __forceinline__ void conv_board_row(f32x4 (&acc)[NT][2], u32x4 (&bh)[
                 bl[fill][0] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, sn, 0);
                 bl[fill][1] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff + 256, sn, 0);
             }
+#endif
             static_for<NT>([&](auto T) __attribute__((always_inline)) {       // fragments of the next step
                 constexpr int t = decltype(T)::value;
                 if constexpr (G::live(t, KH)) {
@@ -1225,7 +349,9 @@ __global__ __launch_bounds__(256, 2) void conv_board_split_kernel(const u64 *__r
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     NNB_SP_STAMP(0) NNB_SP_WALL(5)
 
-    // ---- leaf encode + 2->128 layer into the first image (32x32x16 tiles of 32 cells, as in the other forms) ----
+    // ---- leaf encode (AlphaZeroAgent.preprocess, agent_code.py:76-89) + 2->128 layer (network.py:29-30) into the first
+    //      image, with the layer's static output scale: the two planes are expanded from the bitboards into the A operand
+    //      of 32x32x16 tiles of 32 cells (k = plane*16 + kh*4 + kw; lane half h holds k%16 in [8h, 8h+8)) ----
     for (int e = tid; e < NPOS1 * SP_RS; e += 256) lds[e] = zero4;
     __syncthreads();
     {
@@ -1819,43 +945,17 @@ __global__ void split_to_f32_kernel(const _Float16 *__restrict__ act, const floa
 // ---------------------------------------------------------------------------
 static inline int cdiv_sp(int a, int b) { return (a + b - 1) / b; }
 
-// Up to this many rows the latency-oriented forms run (one board per convolution block, one wave per linear-layer
-// block).  Measured whole forward passes, small / large forms: 128 rows 86 / 176 us, 256 rows 129 / 181 us,
-// 384 rows 198 / 193 us, 512 rows 246 / 198 us (tools/net_latency.py).
-constexpr int kSplitSmallConv = 256, kSplitSmallFc = 256;
-#ifndef NNB_CONV_BOARD
-#define NNB_CONV_BOARD 1
-#endif
-constexpr int CS_NB = 3;
-constexpr size_t C2S_SPLIT_LDS = conv_split_lds_bytes(7, 8, CS_NB);
-constexpr size_t C4S_SPLIT_LDS = conv_split_lds_bytes(8, 9, CS_NB);
-constexpr size_t CPS_SPLIT_LDS = conv_pair_lds_bytes(CS_NB);
-static_assert(C4S_SPLIT_LDS <= 160 * 1024, "the image of one block must fit the LDS of a CU");
+// Up to this many rows the linear layer runs its latency-oriented form (one wave per block); the convolution kernel
+// is one board per block at every batch size.  Whole forward passes: tools/net_latency.py.
+constexpr int kSplitSmallFc = 256;
+static_assert(2 * conv_board_lds_bytes() <= 160 * 1024, "two blocks of the convolution kernel share a CU");
 
 hipError_t prepare_net_kernels_split() {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_board_split_kernel<4, false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_pair_small_lds_bytes());
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_board_lds_bytes());
     if (err != hipSuccess) return err;
-    err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_board_split_kernel<4, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_pair_small_lds_bytes());
-    if (err != hipSuccess) return err;
-    err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rows_split_kernel<7, 8, CS_NB, 4, 8, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)C2S_SPLIT_LDS);
-    if (err != hipSuccess) return err;
-    err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rows_split_kernel<8, 9, CS_NB, 4, 8, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C4S_SPLIT_LDS);
-    if (err != hipSuccess) return err;
-    err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pair_split_kernel<CS_NB, 4, 8, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)CPS_SPLIT_LDS);
-    if (err != hipSuccess) return err;
-    err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pair_split_kernel<CS_NB, 4, 8, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)CPS_SPLIT_LDS);
-    if (err != hipSuccess) return err;
-    err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pair_split_small_kernel<4, 8, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_pair_small_lds_bytes());
-    if (err != hipSuccess) return err;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pair_split_small_kernel<4, 8, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_pair_small_lds_bytes());
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(conv_board_split_kernel<4, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_board_lds_bytes());
 }
 
 void launch_repack_split(hipStream_t st, const NetWeights &dst, const float *conv0_w, const float *conv0_b,
@@ -1883,57 +983,17 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
     if (n_max <= 0) return;
     u32x4 *a2 = reinterpret_cast<u32x4 *>(b.act2), *a3 = reinterpret_cast<u32x4 *>(b.act3);
     switch (stage) {
-    case NET_CONV0:
-        break;      // fused into the first 128->128 layer below
-    case NET_CONV2:
-        conv_rows_split_kernel<7, 8, CS_NB, 4, 8, true><<<cdiv_sp(n_max, CS_NB), 256, C2S_SPLIT_LDS, st>>>(
-            nullptr, nullptr, (const u32x4 *)w.conv2_wh, (const u32x4 *)w.conv2_wl, w.conv2_b, w.sp_scales, a2,
-            b.act2_inv, count_ptr, n_max, side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b);
-        break;
-    case NET_CONV_PAIR:         // both 128->128 layers (and the 2->128 one) in one launch; act2 stays in LDS
-#if NNB_CONV_BOARD
-        conv_board_split_kernel<4, false><<<n_max, 256, conv_pair_small_lds_bytes(), st>>>(
+    case NET_CONV_PAIR:         // all three convolutions in one launch; the activations between them stay in LDS
+        conv_board_split_kernel<4, false><<<n_max, 256, conv_board_lds_bytes(), st>>>(
             side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
             (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b,
             w.sp_scales, nullptr, nullptr, a3, b.act3_inv, count_ptr, n_max, b.clk);
         break;
-#endif
-        if (n_max <= kSplitSmallConv) {                          // one board per block
-            conv_pair_split_small_kernel<4, 8, false><<<n_max, 256, conv_pair_small_lds_bytes(), st>>>(
-                side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
-                (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b,
-                w.sp_scales, nullptr, nullptr, a3, b.act3_inv, count_ptr, n_max);
-            break;
-        }
-        conv_pair_split_kernel<CS_NB, 4, 8, false><<<cdiv_sp(n_max, CS_NB), 256, CPS_SPLIT_LDS, st>>>(
-            side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
-            (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b, w.sp_scales,
-            nullptr, nullptr, a3, b.act3_inv, count_ptr, n_max, b.clk);
-        break;
-    case NET_CONV_PAIR_MID:     // the same, and the middle activations are copied out as the two-launch form leaves them
-#if NNB_CONV_BOARD
-        conv_board_split_kernel<4, true><<<n_max, 256, conv_pair_small_lds_bytes(), st>>>(
+    case NET_CONV_PAIR_MID:     // the same, and the 8x9 activations are copied out (nnb_debug_activations)
+        conv_board_split_kernel<4, true><<<n_max, 256, conv_board_lds_bytes(), st>>>(
             side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
             (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b,
             w.sp_scales, a2, b.act2_inv, a3, b.act3_inv, count_ptr, n_max, b.clk);
-        break;
-#endif
-        if (n_max <= kSplitSmallConv) {
-            conv_pair_split_small_kernel<4, 8, true><<<n_max, 256, conv_pair_small_lds_bytes(), st>>>(
-                side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
-                (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b,
-                w.sp_scales, a2, b.act2_inv, a3, b.act3_inv, count_ptr, n_max);
-            break;
-        }
-        conv_pair_split_kernel<CS_NB, 4, 8, true><<<cdiv_sp(n_max, CS_NB), 256, CPS_SPLIT_LDS, st>>>(
-            side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
-            (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b, w.sp_scales,
-            a2, b.act2_inv, a3, b.act3_inv, count_ptr, n_max, b.clk);
-        break;
-    case NET_CONV4:
-        conv_rows_split_kernel<8, 9, CS_NB, 4, 8, false><<<cdiv_sp(n_max, CS_NB), 256, C4S_SPLIT_LDS, st>>>(
-            a2, b.act2_inv, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b, w.sp_scales, a3,
-            b.act3_inv, count_ptr, n_max, nullptr, nullptr, nullptr, nullptr);
         break;
     case NET_FC: {
         const FcFinish fin = {w.fc_b, w.heads_w, b.fcq, b.write_hidden ? b.fc : nullptr, b.fchand, b.fcsync, b.fcsync + b.fc_pairs,

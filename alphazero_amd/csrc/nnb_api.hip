@@ -18,11 +18,6 @@
 
 using namespace nnb;
 
-#ifndef NNB_CONV_BOARD
-#define NNB_CONV_BOARD 1
-#endif
-#define NNB_CONV_BOARD_FORM NNB_CONV_BOARD      // 1: the one-board-per-block convolutions serve every call (no two-launch form)
-
 namespace {
 
 thread_local char g_err[512] = "";
@@ -109,7 +104,6 @@ struct nnb_engine {
     long long stream_prev[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // cumulative statistics as of the last call's end
     nnb_search_params stream_params = {};
     RoundDev stream_round = {};
-    bool separate_convs = false;           // NNB_FLAG_SEPARATE_CONVS of the call in progress
     bool policy_heads = true;              // the search in progress reads the policy heads (PUCT), not only the value
     bool shared_chip = false;              // two forward passes run side by side on two streams
     int row_bound = 0;                     // > 0: no leaf batch of the rounds being launched holds more rows than this
@@ -305,7 +299,6 @@ SearchDev to_dev(const nnb_search_params &p) {
 int check_params(nnb_engine *e, const nnb_search_params *p, int n) {
     if (!e) return fail(NNB_ERR_ARG, "engine is null");
     if (!p) return fail(NNB_ERR_ARG, "params is null");
-    e->separate_convs = (p->flags & NNB_FLAG_SEPARATE_CONVS) != 0;
     e->row_bound = 0;
     e->shared_chip = false;
     if (n < 1 || n > e->cfg.max_games)
@@ -388,8 +381,8 @@ void forward_leaves(nnb_engine *e, hipStream_t st, int weight_set, int batch, in
     const size_t o = (size_t)batch * d.max_games;
     const bool fused_in = e->cfg.net_precision != NNB_NET_F32;     // conv0 is part of the conv2 launch there
     if (!fused_in) { ProfScope ps(e, 1, st); net_stage(e, st, NET_CONV0, w, nb, d.leaf_side + 2 * o, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
-    if (e->cfg.net_precision == NNB_NET_F32S && !(e->separate_convs && !NNB_CONV_BOARD_FORM)) {
-        // both 128->128 layers in one launch (timed as class 2; class 3 stays empty)
+    if (e->cfg.net_precision == NNB_NET_F32S) {
+        // all three convolutions in one launch (timed as class 2; class 3 stays empty)
         ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV_PAIR, w, nb, d.leaf_side + 2 * o, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max);
     } else {
         { ProfScope ps(e, 2, st); net_stage(e, st, NET_CONV2, w, nb, d.leaf_side + 2 * o, nullptr, nullptr, nullptr, nullptr, count_ptr, n_max); }
@@ -1046,7 +1039,6 @@ int nnb_selfplay_stream(nnb_engine *e, void *stream, const nnb_search_params *pa
                     "(at most ring_len - 2 x max_games = %d per call)", min_finished,
                     e->stream_round.ring_len - 2 * e->stream_slots);
     const nnb_search_params &p = e->stream_params;
-    e->separate_convs = (p.flags & NNB_FLAG_SEPARATE_CONVS) != 0;
     e->dev.n_games = e->stream_slots;
     int make_noise = 0;
     (void)noise_wanted(p, &make_noise);

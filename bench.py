@@ -366,7 +366,7 @@ def main():
             # the float32-faithful path runs conv0 + conv2 + conv4 as ONE launch, timed as "conv2"
             FLOP_PER_LEAF["conv2"] += FLOP_PER_LEAF.pop("conv0") + FLOP_PER_LEAF.pop("conv4")
             FLOP_PER_LEAF["conv0"] = FLOP_PER_LEAF["conv4"] = 0
-            KERNEL_NAME["conv2"] = "conv0+conv2+conv4 (conv_pair_split_kernel)"
+            KERNEL_NAME["conv2"] = "conv0+conv2+conv4 (conv_board_split_kernel)"
         dom = max(FLOP_PER_LEAF, key=lambda k: shares.get(k, 0.0))
         avg_ms = prof[dom]["avg_ms"]
         achieved = (leaves_per_launch * FLOP_PER_LEAF[dom]) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0

@@ -95,9 +95,8 @@ enum nnb_flags {
      * NNB_NET_F16 (where it measured slower).  ONE_STREAM / TWO_STREAMS force the choice. */
     NNB_FLAG_ONE_STREAM = 16,
     NNB_FLAG_TWO_STREAMS = 32,
-    /* NET evaluator with NNB_NET_F32S: run the two 128->128 convolutions as two launches with the
-     * activations between them in memory, instead of one launch that keeps them in LDS.  Same results
-     * bit for bit; exists so the two forms can be checked against each other. */
+    /* Accepted and ignored (it once selected a two-launch form of the NNB_NET_F32S convolutions; one kernel now
+     * serves every batch size, so a position's outputs cannot depend on the form that evaluated it). */
     NNB_FLAG_SEPARATE_CONVS = 64
 };
 

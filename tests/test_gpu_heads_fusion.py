@@ -49,47 +49,35 @@ def test_fused_and_separate_heads_agree(rp, precision, mode):
         eng.close()
 
 
-@pytest.mark.parametrize("mode", ["compat", "az"])
-def test_one_launch_and_two_launch_convolutions_agree(rp, mode):
-    """Float32-faithful path: the two 128->128 convolutions (network.py:31-34) as one launch with the
-    activations between them kept in LDS, against two launches with those activations in memory.  The
-    halves and per-board scales are the same, so games and root values must be the same bit for bit; the
-    network entry point (one launch that also copies the middle activations out) must agree with the
-    leaf values both forms fed the searches."""
-    from alphazero_amd.engine import Engine, trajectories_to_numpy
+def test_search_backs_up_the_value_the_network_entry_point_returns(rp):
+    """Float32-faithful path: a one-simulation search in the reference's rule backs up exactly the network's value of
+    the root position as seen by the mover (agent_code.py:195-212).  The search (leaf batch through the lock-step
+    forward pass, value head only) and nnb_net_forward (all heads, hidden activations copied out) must give the same
+    float for every one of 100 positions, 33 whole row tiles of the linear layer's small form and one partial."""
+    from alphazero_amd.engine import Engine
     from alphazero_amd.selfplay import random_openings
-    eng = Engine(max_games=100, max_sims=32, precision="f32s")      # 100 slots: 33 full blocks of 3 boards and one of 1
+    eng = Engine(max_games=100, max_sims=32, precision="f32s")
     try:
         eng.load_state_dict(rp.seeded_state_dict(0), 0)
-        n = 160
-        sb, sp = random_openings(eng, n, 6, seed=21)
-        extra = dict(dirichlet_alpha=0.3, dirichlet_eps=0.25, seed=5) if mode == "az" else {}
-        out = []
-        for separate in (False, True):
-            prm = eng.params(32, 1.4, evaluator="net", mode=mode, separate_convs=separate, **extra)
-            traj, stats = eng.selfplay_round(n, prm, start_boards=sb, start_players=sp)
-            out.append((trajectories_to_numpy(traj).copy(), stats))
-        assert out[0][0].tobytes() == out[1][0].tobytes()
-        assert out[0][1] == out[1][1]
-        assert len({r["plies"]["action"][:r["length"]].tobytes() for r in out[0][0]}) > 40
-        a = eng.search(sb[:100], sp[:100], eng.params(32, 1.4, evaluator="net", mode=mode, **extra))
-        b = eng.search(sb[:100], sp[:100], eng.params(32, 1.4, evaluator="net", mode=mode, separate_convs=True, **extra))
-        assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[2].tobytes() == b[2].tobytes()
-        # a one-simulation search in the reference's rule backs up exactly the network's value of the root position
-        # as seen by the mover (agent_code.py:195-212): the network entry point must give the same float
-        one = eng.search(sb[:100], sp[:100], eng.params(1, 1.4, evaluator="net", mode="compat"))
-        side = np.where(sp[:100, None] == 1, sb[:100], sb[:100, ::-1]).astype(np.uint64)
+        sb, sp = random_openings(eng, 100, 6, seed=21)
+        one = eng.search(sb, sp, eng.params(1, 1.4, evaluator="net", mode="compat"))
+        side = np.where(sp[:, None] == 1, sb, sb[:, ::-1]).astype(np.uint64)
         _, value, _ = eng.net_forward(side)
         assert np.asarray(one[2], dtype=np.float64).tobytes() == value.cpu().numpy().astype(np.float64).tobytes()
+        # the retired two-launch flag is accepted and changes nothing
+        a = eng.search(sb, sp, eng.params(32, 1.4, evaluator="net"))
+        b = eng.search(sb, sp, eng.params(32, 1.4, evaluator="net", separate_convs=True))
+        assert (a[0] == b[0]).all() and a[2].tobytes() == b[2].tobytes()
     finally:
         eng.close()
 
 
 @pytest.mark.parametrize("precision", ["f32s", "f16"])
 def test_small_batch_and_large_batch_kernels_agree_bit_for_bit(rp, precision):
-    """Batches of at most 128 (half inputs) or 256 (float32-faithful) positions run latency-oriented forms of the network kernels (one board per
-    convolution block, one wave per linear-layer block); larger ones the throughput forms.  A position's
-    outputs and hidden activations must not depend on which form evaluated it."""
+    """Batches of at most 128 (half inputs) or 256 (float32-faithful) positions run latency-oriented forms of the
+    network kernels (half inputs: one board per convolution block; both: one wave per linear-layer block); larger
+    ones the throughput forms.  A position's outputs and hidden activations must not depend on which form
+    evaluated it."""
     import torch
     from alphazero_amd.engine import Engine
     from alphazero_amd.selfplay import random_openings

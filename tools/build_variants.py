@@ -18,10 +18,8 @@ VARIANTS = {
     "look32": ["-DNNB_LOOK_ROUNDS=32"],
     "look128": ["-DNNB_LOOK_ROUNDS=128"],
     "look256": ["-DNNB_LOOK_ROUNDS=256"],
-    "conv3": ["-DNNB_CONV_BOARD=0"],                # the three-boards-per-block convolutions
 }
-AFFECTED = {"NNB_TERMINAL_SIMS_PER_STEP": ["tree_kernels.hip"], "NNB_LOOK_ROUNDS": ["nnb_api.hip"],
-            "NNB_CONV_BOARD": ["net_kernels_split.hip", "nnb_api.hip"]}
+AFFECTED = {"NNB_TERMINAL_SIMS_PER_STEP": ["tree_kernels.hip"], "NNB_LOOK_ROUNDS": ["nnb_api.hip"]}
 
 
 def main():

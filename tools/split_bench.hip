@@ -24,13 +24,6 @@ template <typename T> T *dev_random_halves(size_t n_halves, float lo, float hi, 
     return (T *)d;
 }
 
-static void report(const char *name, float us, double flop) {
-    unsigned long long h[8]; CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sp_clk), sizeof h));
-    double mhz = (h[6] > h[5]) ? (double)(h[3] - h[0]) / (double)(h[6] - h[5]) * 100.0 : 0.0;
-    printf("%-34s %8.1f us  %7.1f TFLOP/s   block: stage %6llu  main %7llu  epilogue %6llu (relu+max %llu, tile %llu, copy-out %llu) cycles  clock %.0f MHz\n", name, us,
-           flop / (us * 1e-6) / 1e12, h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[2], h[7] - h[4], h[3] - h[7], mhz);
-}
-
 int main(int argc, char **argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 3979, iters = 20;
     u32x4 *act2 = dev_random_halves<u32x4>((size_t)n * 72 * 256, 0.f, 1.f, 1);
@@ -66,83 +59,24 @@ int main(int argc, char **argv) {
         float ms; CK(hipEventElapsedTime(&ms, a, b)); CK(hipGetLastError());
         return ms / iters * 1000.f;
     };
-    float us = time_it([&] {
-        conv_rows_split_kernel<7, 8, CS_NB, 4, 8, true><<<cdiv_sp(n, CS_NB), 256, C2S_SPLIT_LDS, 0>>>(
-            nullptr, nullptr, w2h, w2l, bias, sc, act2o, inv_o, nullptr, n, side, w0h, w0l, bias);
-    });
-    report("conv 7x8->8x9 (+2->128 fused)", us, (double)n * 2 * 128 * 72 * 2048);
-    us = time_it([&] {
-        conv_rows_split_kernel<8, 9, CS_NB, 4, 8, false><<<cdiv_sp(n, CS_NB), 256, C4S_SPLIT_LDS, 0>>>(
-            act2, inv, w2h, w2l, bias, sc, act3, inv_o, nullptr, n, nullptr, nullptr, nullptr, nullptr);
-    });
-    report("conv 8x9->9x10", us, (double)n * 2 * 128 * 90 * 2048);
-    us = time_it([&] {
-        conv_pair_split_kernel<CS_NB, 4, 8, false><<<cdiv_sp(n, CS_NB), 256, CPS_SPLIT_LDS, 0>>>(
-            side, w0h, w0l, bias, w2h, w2l, bias, w2h, w2l, bias, sc, nullptr, nullptr, act3, inv_o, nullptr, n, nullptr);
-    });
-    {
-        unsigned long long h[8]; CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sp_clk), sizeof h));
-        printf("both convs in one launch          %8.1f us  %7.1f TFLOP/s   block: 2->128 %llu  main1 %llu  epilogue1 %llu  main2 %llu  epilogue2 %llu  total %llu cycles  clock %.0f MHz\n",
-               us, (double)n * 2 * 128 * (72 + 90) * 2048 / (us * 1e-6) / 1e12, h[1] - h[0], h[2] - h[1], h[4] - h[2], h[7] - h[4], h[3] - h[7], h[3] - h[0],
-               (double)(h[3] - h[0]) / (double)(h[6] - h[5]) * 100.0);
-    }
-    {   // one board per block, 16-cell tiles (two blocks per CU): time, and its output against the form above
-        const int nc = n < 64 ? n : 64;
-        std::vector<float> ref((size_t)nc * 90 * 128), got((size_t)nc * 90 * 128);
-        float *f32; CK(hipMalloc((void **)&f32, ref.size() * 4));
-        launch_split_to_f32(0, act3, inv_o, 90, nc, f32);
-        CK(hipMemcpy(ref.data(), f32, ref.size() * 4, hipMemcpyDeviceToHost));
-        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_board_split_kernel<4, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_pair_small_lds_bytes()));
+    {   // all three convolutions: one board per block, 16-cell tiles, two blocks per CU
         CK(hipMemset(act3, 0, (size_t)n * 90 * 512));
         float t = time_it([&] {
-            conv_board_split_kernel<4, false><<<n, 256, conv_pair_small_lds_bytes(), 0>>>(
+            conv_board_split_kernel<4, false><<<n, 256, conv_board_lds_bytes(), 0>>>(
                 side, w0h, w0l, bias, w2h, w2l, bias, w2h, w2l, bias, sc, nullptr, nullptr, act3, inv_o, nullptr, n, nullptr);
         });
+        // a checksum of the first boards' outputs, so that two builds of the kernel can be compared
+        const int nc = n < 64 ? n : 64;
+        std::vector<float> got((size_t)nc * 90 * 128);
+        float *f32; CK(hipMalloc((void **)&f32, got.size() * 4));
         launch_split_to_f32(0, act3, inv_o, 90, nc, f32);
         CK(hipMemcpy(got.data(), f32, got.size() * 4, hipMemcpyDeviceToHost));
-        double worst = 0.0, big = 0.0;
-        for (size_t i = 0; i < ref.size(); ++i) { worst = fmax(worst, fabs((double)ref[i] - got[i])); big = fmax(big, fabs((double)ref[i])); }
+        double sum = 0.0, big = 0.0;
+        for (float v : got) { sum += v; big = fmax(big, fabs((double)v)); }
         unsigned long long h[8]; CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sp_clk), sizeof h));
-        printf("both convs, one board per block, 16-cell tiles:  %8.1f us  %7.1f TFLOP/s   block: 2->128 %llu  main1 %llu  epilogue1 %llu  main2 %llu  epilogue2 %llu  total %llu cycles  clock %.0f MHz;  max |diff| to the form above %.3g of max %.3g\n",
+        printf("convolutions (2->128, 7x8->8x9, 8x9->9x10), one board per block: %8.1f us  %7.1f TFLOP/s   block: 2->128 %llu  main1 %llu  epilogue1 %llu  main2 %llu  epilogue2 %llu  total %llu cycles  clock %.0f MHz;  output sum %.9g max %.6g\n",
                t, (double)n * 2 * 128 * (72 + 90) * 2048 / (t * 1e-6) / 1e12, h[1] - h[0], h[2] - h[1], h[4] - h[2], h[7] - h[4], h[3] - h[7], h[3] - h[0],
-               (double)(h[3] - h[0]) / (double)(h[6] - h[5]) * 100.0, worst, big);
-    }
-    {   // the one-board-per-block form (two blocks per CU, 29 % more MFMAs) on the full batch: does a second resident block
-        // fill the matrix pipe's idle phases, and what does the clock do then?
-        float t = time_it([&] {
-            conv_pair_split_small_kernel<4, 8, false><<<n, 256, conv_pair_small_lds_bytes(), 0>>>(
-                side, w0h, w0l, bias, w2h, w2l, bias, w2h, w2l, bias, sc, nullptr, nullptr, act3, inv_o, nullptr, n);
-        });
-        printf("both convs, one board per block, 2 blocks per CU: %8.1f us  (2304 MFMAs per wave and board against 1792)\n", t);
-    }
-    {   // two half batches on two streams (conv 7x8 + conv 8x9 each) against the same work on one stream
-        hipStream_t s1, s2; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-        const int nh = n / 2;
-        auto half = [&](hipStream_t st, int off, int cnt) {
-            conv_rows_split_kernel<7, 8, CS_NB, 4, 8, true><<<cdiv_sp(cnt, CS_NB), 256, C2S_SPLIT_LDS, st>>>(
-                nullptr, nullptr, w2h, w2l, bias, sc, act2o + (size_t)off * 72 * 32, inv_o + off, nullptr, cnt, side + 2 * off, w0h, w0l, bias);
-            conv_rows_split_kernel<8, 9, CS_NB, 4, 8, false><<<cdiv_sp(cnt, CS_NB), 256, C4S_SPLIT_LDS, st>>>(
-                act2 + (size_t)off * 72 * 32, inv + off, w2h, w2l, bias, sc, act3 + (size_t)off * 90 * 32, inv_o + off, nullptr, cnt, nullptr, nullptr, nullptr, nullptr);
-        };
-        hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
-        for (int rep = 0; rep < 2; ++rep) {
-            CK(hipDeviceSynchronize());
-            CK(hipEventRecord(e0, s1)); CK(hipStreamWaitEvent(s2, e0, 0));
-            for (int i = 0; i < iters; ++i) { half(s1, 0, nh); half(s2, nh, n - nh); }
-            CK(hipEventRecord(e2, s2)); CK(hipStreamWaitEvent(s1, e2, 0)); CK(hipEventRecord(e1, s1));
-            CK(hipEventSynchronize(e1));
-            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            if (rep) printf("two convs, half batches on two streams: %8.1f us per full batch\n", ms / iters * 1000.f);
-        }
-        for (int rep = 0; rep < 2; ++rep) {
-            CK(hipDeviceSynchronize());
-            CK(hipEventRecord(e0, s1));
-            for (int i = 0; i < iters; ++i) half(s1, 0, n);
-            CK(hipEventRecord(e1, s1)); CK(hipEventSynchronize(e1));
-            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            if (rep) printf("two convs, full batch on one stream:    %8.1f us per full batch\n", ms / iters * 1000.f);
-        }
+               (double)(h[3] - h[0]) / (double)(h[6] - h[5]) * 100.0, sum, big);
     }
     u32x4 *a3 = dev_random_halves<u32x4>((size_t)n * 90 * 256, 0.f, 1.f, 8);
     auto fc_run = [&](auto BRc, auto ABLc, int rows) {

@@ -27,7 +27,7 @@ def kernel_class(name: str):
     if "tree_fused_kernel" in name: return "tree_fused"
     if "readout_kernel" in name: return "readout"
     if "conv_in_kernel" in name: return "conv0"
-    if "conv_pair" in name: return "conv2"       # conv0 + conv2 + conv4 in one launch; bench.py times it as conv2
+    if "conv_pair" in name or "conv_board" in name: return "conv2"       # conv0 + conv2 + conv4 in one launch; bench.py times it as conv2
     if "conv_rows" in name:
         return "conv2" if any(t in name for t in ("<7, 8", "<7,8", "ILi7ELi8E")) else "conv4"
     if "conv_mid" in name:
