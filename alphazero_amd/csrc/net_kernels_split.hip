@@ -117,9 +117,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t conv_weight_rsrc(const u32x4 *
 #ifdef NNB_SPLIT_BENCH_CLOCKS
 // timing harness only (tools/split_bench.hip): shader-clock stamps of one block's phases
 __device__ unsigned long long g_sp_clk[8];
+__device__ unsigned long long g_sp_block_t[2 * 8192];         // wall clock (100 MHz) at the start and end of every block
 #define NNB_SP_BLOCK 100
 #define NNB_SP_STAMP(i) if (blockIdx.x == NNB_SP_BLOCK && threadIdx.x == 0) g_sp_clk[i] = __builtin_readcyclecounter();
-#define NNB_SP_WALL(i) if (blockIdx.x == NNB_SP_BLOCK && threadIdx.x == 0) g_sp_clk[i] = wall_clock64();
+#define NNB_SP_WALL(i) { if (blockIdx.x == NNB_SP_BLOCK && threadIdx.x == 0) g_sp_clk[i] = wall_clock64(); \
+                         if (threadIdx.x == 0 && blockIdx.x < 8192) g_sp_block_t[2 * blockIdx.x + ((i) == 6)] = wall_clock64(); }
 #else
 #define NNB_SP_STAMP(i)
 #define NNB_SP_WALL(i)
