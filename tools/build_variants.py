@@ -15,6 +15,8 @@ from alphazero_amd.build import COMMON, CSRC, SOURCES, _hipcc  # noqa: E402
 VARIANTS = {
     "ts3": ["-DNNB_TERMINAL_SIMS_PER_STEP=3"],
     "ts10": ["-DNNB_TERMINAL_SIMS_PER_STEP=10"],
+    "ts16": ["-DNNB_TERMINAL_SIMS_PER_STEP=16"],
+    "ts32": ["-DNNB_TERMINAL_SIMS_PER_STEP=32"],
     "look32": ["-DNNB_LOOK_ROUNDS=32"],
     "look128": ["-DNNB_LOOK_ROUNDS=128"],
     "look256": ["-DNNB_LOOK_ROUNDS=256"],
