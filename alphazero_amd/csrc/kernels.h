@@ -86,6 +86,10 @@ struct NetBuffers {            // activations, channels-last float32
     float *fchand, *fchand_b1;
     uint32_t *fcsync, *fcsync_b1;
     int32_t *sync_err;
+    // split-operand path, a handful of boards (at most kConvSpreadMaxBoards): four blocks share a board's convolutions
+    // and meet through float32 activations [boards][(72 + 90) * 128] and two maximum words per board (zero between passes)
+    float *spread_f32, *spread_f32_b1;
+    uint32_t *spread_max, *spread_max_b1;
     int fc_pairs;              // ticket words per batch (the flag words follow them)
     int heads_all;             // 1: the linear layer's last step produces all 8 heads, 0: the value head only
     int write_hidden;          // 1: it also writes the hidden activations to `fc`
@@ -101,6 +105,9 @@ enum NetStage { NET_CONV0 = 0, NET_CONV2 = 1, NET_CONV4 = 2, NET_FC = 3, NET_HEA
                 // float32-faithful path only: NET_CONV0 + NET_CONV2 + NET_CONV4 as one launch (the activations between the
                 // two 128->128 layers stay in LDS), and the same with those activations also copied out
                 NET_CONV_PAIR = 5, NET_CONV_PAIR_MID = 6 };
+
+constexpr int kConvSpreadMaxBoards = 64;
+constexpr int kConvSpreadFloatsPerBoard = (72 + 90) * 128;
 
 // Ticket / flag words of the linear layer's block pairs for G rows: the large-batch form pairs (row block of 32..128
 // rows, 256-column block), the small-batch form (32-row tile, 32-column tile) for at most 256 rows.

@@ -318,39 +318,18 @@ __device__ __forceinline__ void conv_board_store(const f32x4 (&acc)[NT][2], floa
     });
 }
 
-template <int BRING, bool WRITE_MID>
-__global__ __launch_bounds__(256, 2) void conv_board_split_kernel(const u64 *__restrict__ side,
-                                                                  const u32x4 *__restrict__ w0h, const u32x4 *__restrict__ w0l,
-                                                                  const float *__restrict__ b0,
-                                                                  const u32x4 *__restrict__ w2h, const u32x4 *__restrict__ w2l,
-                                                                  const float *__restrict__ bias2,
-                                                                  const u32x4 *__restrict__ w4h, const u32x4 *__restrict__ w4l,
-                                                                  const float *__restrict__ bias4,
-                                                                  const SplitScales *__restrict__ sc,
-                                                                  u32x4 *__restrict__ mid, float *__restrict__ mid_inv_scale,
-                                                                  u32x4 *__restrict__ out, float *__restrict__ out_inv_scale,
-                                                                  const int32_t *__restrict__ count_ptr, int n_fixed,
-                                                                  unsigned long long *__restrict__ clk) {
+// Leaf encode (AlphaZeroAgent.preprocess, agent_code.py:76-89) + the 2->128 layer (network.py:29-30) into the image of
+// the 7x8 -> 8x9 layer at `smem_raw`, by a block of 256 threads (wave w forms output channels 32w .. 32w+31); the caller
+// synchronises the block afterwards.
+__device__ __forceinline__ void conv_first_image(unsigned char *smem_raw, const u64 *__restrict__ side, int board,
+                                                 const u32x4 *__restrict__ w0h, const u32x4 *__restrict__ w0l,
+                                                 const float *__restrict__ b0, const SplitScales *__restrict__ sc, int tid) {
     using G1 = BoardGeom<7, 8>;
-    using G2 = BoardGeom<8, 9>;
     constexpr int PB = SP_PB;
     constexpr int IW1 = 8, IP1 = 56, W21 = G1::W2, LEAD1 = G1::LEAD, NPOS1 = G1::NPOS;
-    constexpr int IH2 = 8, IW2 = 9, IP2 = 72, W22 = G2::W2, LEAD2 = G2::LEAD, NPOS2 = G2::NPOS;
-    constexpr int OP2 = G2::NC;
-    constexpr int REGION = (NPOS2 > NPOS1 ? (NPOS2 > OP2 ? NPOS2 : OP2) : (NPOS1 > OP2 ? NPOS1 : OP2)) * PB;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4 *lds = reinterpret_cast<u32x4 *>(smem_raw);
-    float *s_max = reinterpret_cast<float *>(smem_raw + REGION);     // [4 waves]
-    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter(); clk[1] = wall_clock64(); }
-
-    const int count = batch_count_sp(count_ptr, n_fixed);
-    const int board = blockIdx.x;
-    if (board >= count) return;
-    const int tid = threadIdx.x;
     const int lane = tid & 63, nt = tid >> 6, m = lane & 31, h = lane >> 5;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    NNB_SP_STAMP(0) NNB_SP_WALL(5)
-
     // ---- leaf encode (AlphaZeroAgent.preprocess, agent_code.py:76-89) + 2->128 layer (network.py:29-30) into the first
     //      image, with the layer's static output scale: the two planes are expanded from the bitboards into the A operand
     //      of 32x32x16 tiles of 32 cells (k = plane*16 + kh*4 + kw; lane half h holds k%16 in [8h, 8h+8)) ----
@@ -402,6 +381,42 @@ __global__ __launch_bounds__(256, 2) void conv_board_split_kernel(const u64 *__r
             }
         }
     }
+}
+
+template <int BRING, bool WRITE_MID>
+__global__ __launch_bounds__(256, 2) void conv_board_split_kernel(const u64 *__restrict__ side,
+                                                                  const u32x4 *__restrict__ w0h, const u32x4 *__restrict__ w0l,
+                                                                  const float *__restrict__ b0,
+                                                                  const u32x4 *__restrict__ w2h, const u32x4 *__restrict__ w2l,
+                                                                  const float *__restrict__ bias2,
+                                                                  const u32x4 *__restrict__ w4h, const u32x4 *__restrict__ w4l,
+                                                                  const float *__restrict__ bias4,
+                                                                  const SplitScales *__restrict__ sc,
+                                                                  u32x4 *__restrict__ mid, float *__restrict__ mid_inv_scale,
+                                                                  u32x4 *__restrict__ out, float *__restrict__ out_inv_scale,
+                                                                  const int32_t *__restrict__ count_ptr, int n_fixed,
+                                                                  unsigned long long *__restrict__ clk) {
+    using G1 = BoardGeom<7, 8>;
+    using G2 = BoardGeom<8, 9>;
+    constexpr int PB = SP_PB;
+    constexpr int NPOS1 = G1::NPOS;
+    constexpr int IH2 = 8, IW2 = 9, IP2 = 72, W22 = G2::W2, LEAD2 = G2::LEAD, NPOS2 = G2::NPOS;
+    constexpr int OP2 = G2::NC;
+    constexpr int REGION = (NPOS2 > NPOS1 ? (NPOS2 > OP2 ? NPOS2 : OP2) : (NPOS1 > OP2 ? NPOS1 : OP2)) * PB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4 *lds = reinterpret_cast<u32x4 *>(smem_raw);
+    float *s_max = reinterpret_cast<float *>(smem_raw + REGION);     // [4 waves]
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter(); clk[1] = wall_clock64(); }
+
+    const int count = batch_count_sp(count_ptr, n_fixed);
+    const int board = blockIdx.x;
+    if (board >= count) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, nt = tid >> 6;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    NNB_SP_STAMP(0) NNB_SP_WALL(5)
+
+    conv_first_image(smem_raw, side, board, w0h, w0l, b0, sc, tid);
     __syncthreads();
     NNB_SP_STAMP(1)
 
@@ -466,6 +481,250 @@ __global__ __launch_bounds__(256, 2) void conv_board_split_kernel(const u64 *__r
     if (tid == 0) out_inv_scale[board] = sinv;
     NNB_SP_STAMP(3) NNB_SP_WALL(6)
     if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[2] = __builtin_readcyclecounter(); clk[3] = wall_clock64(); }
+}
+
+// ---------------------------------------------------------------------------
+// The same convolutions for a HANDFUL of boards (at most kSpreadMaxBoards: single searches, small tournaments), where
+// only latency counts: conv_board_split_kernel gives a board to one block, whose four waves each walk 5 or 6 tiles x 2
+// channel tiles through 64 weight steps - about 50 us however few boards there are.  Here FOUR blocks share a board and
+// every wave owns one channel tile of 16 and half of the board's cell tiles, in three launches:
+//   conv_spread_first_kernel   leaf encode + 2->128 (every block, whole image) and its 32 channels of the 7x8 -> 8x9
+//                              layer: ReLU(acc * k + bias) as float32 to `mid_f32`, the board's maximum by atomic max
+//   conv_spread_second_kernel  the 8x9 image from `mid_f32` quantised with the board's scale, its 32 channels of the
+//                              8x9 -> 9x10 layer to `out_f32`, the maximum likewise
+//   conv_spread_pack_kernel    `out_f32` quantised with the board's scale into the linear layer's input; clears the maxima
+// Every accumulator sums the products conv_board_split_kernel sums, in its order (kernel rows, taps, k-steps ascending;
+// hi*lo, lo*hi, hi*hi), a maximum does not depend on the order it is taken in, and the scales and the hi / lo split are
+// the same functions of the same float32 values: the outputs equal the one-block form's bit for bit.
+// ---------------------------------------------------------------------------
+constexpr int kSpreadMaxBoards = kConvSpreadMaxBoards;
+constexpr int kSpreadMidFloats = 72 * 128, kSpreadOutFloats = 90 * 128;
+constexpr int kSpreadFloatsPerBoard = kSpreadMidFloats + kSpreadOutFloats;
+static_assert(kSpreadFloatsPerBoard == kConvSpreadFloatsPerBoard, "the workspace holds this many floats per board");
+
+// Kernel row KH for tiles T0 .. T0+TN-1 and ONE channel tile (cf. conv_board_row).  A wave has few matrix instructions
+// per weight step here (at most 9), so the weights run a whole kernel row (16 steps) ahead to cover the L2 latency,
+// and the row is unrolled completely.
+template <int IH, int IW, int T0, int TN, int KH>
+__device__ __forceinline__ void conv_spread_row(f32x4 (&acc)[TN], u32x4 (&bh)[16], u32x4 (&bl)[16],
+                                                const unsigned char *smem, const int (&tbase)[TN],
+                                                const __amdgpu_buffer_rsrc_t &rwh, const __amdgpu_buffer_rsrc_t &rwl, int woff) {
+    using G = BoardGeom<IH, IW>;
+    constexpr int W2 = G::W2, PB = SP_PB;
+    u32x4 ah[2][TN], al[2][TN];
+    const unsigned char *p0 = smem + ((KH - 2) * W2 - 2) * PB;
+    static_for<TN>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+        if constexpr (G::live(T0 + t, KH)) {
+            ah[0][t] = *reinterpret_cast<const u32x4 *>(p0 + tbase[t]);
+            al[0][t] = *reinterpret_cast<const u32x4 *>(p0 + tbase[t] + SP_LO);
+        }
+    });
+    static_for<16>([&](auto Sc) __attribute__((always_inline)) {
+        constexpr int st = decltype(Sc)::value, kw = st >> 2, ks = st & 3;
+        constexpr int cur = st & 1, nxt = cur ^ 1;
+        const u32x4 wh4 = bh[st], wl4 = bl[st];
+        if constexpr (KH < 3) {                                       // the same step of the next kernel row
+            bh[st] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, ((KH + 1) * 16 + st) * 8192, 0);
+            bl[st] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, ((KH + 1) * 16 + st) * 8192, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);                            // the loads stay a row ahead of their use
+        static_for<TN>([&](auto T) __attribute__((always_inline)) {       // fragments of the next step
+            constexpr int t = decltype(T)::value;
+            if constexpr (G::live(T0 + t, KH) && st < 15) {
+                constexpr int off = ks < 3 ? kw * PB + (ks + 1) * 64 : (kw + 1) * PB;
+                ah[nxt][t] = *reinterpret_cast<const u32x4 *>(p0 + off + tbase[t]);
+                al[nxt][t] = *reinterpret_cast<const u32x4 *>(p0 + off + tbase[t] + SP_LO);
+            }
+        });
+        const half8 wh = as_half8(wh4), wl = as_half8(wl4);
+        static_for<TN>([&](auto T) __attribute__((always_inline)) {
+            constexpr int t = decltype(T)::value;
+            if constexpr (G::live(T0 + t, KH)) {
+                const half8 xh = as_half8(ah[cur][t]), xl = as_half8(al[cur][t]);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wh, acc[t], 0, 0, 0);
+            }
+        });
+    });
+}
+
+// One wave's share of a 128->128 layer: tiles T0 .. T0+TN-1, channel tile `ctile` (16 channels), then v = ReLU(acc * k +
+// bias) as float32 to dst[cell][128]; returns the lane's maximum over the valid cells.
+template <int IH, int IW, int T0, int TN>
+__device__ __forceinline__ float conv_spread_layer(const unsigned char *smem, const u32x4 *wph, const u32x4 *wpl,
+                                                   const float *__restrict__ bias, float k, float *__restrict__ dst,
+                                                   int lane, int ctile) {
+    using G = BoardGeom<IH, IW>;
+    static_assert(T0 + TN <= G::NT, "tiles of this layer");
+    const int m = lane & 15, kg = lane >> 4;
+    int tbase[TN];
+    f32x4 acc[TN];
+    static_for<TN>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+        int c = 16 * (T0 + t) + m;
+        c = c < G::NC ? c : G::NC - 1;                           // rows past the last cell repeat it
+        tbase[t] = (G::LEAD + (c / G::OW) * G::W2 + c % G::OW) * SP_PB + kg * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+    });
+    const __amdgpu_buffer_rsrc_t rwh = conv_weight_rsrc(wph), rwl = conv_weight_rsrc(wpl);
+    const int woff = (kg * 128 + ctile * 16 + m) * 16;
+    u32x4 bh[16], bl[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {                              // the first kernel row's weights
+        bh[i] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff, i * 8192, 0);
+        bl[i] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff, i * 8192, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    conv_spread_row<IH, IW, T0, TN, 0>(acc, bh, bl, smem, tbase, rwh, rwl, woff);
+    conv_spread_row<IH, IW, T0, TN, 1>(acc, bh, bl, smem, tbase, rwh, rwl, woff);
+    conv_spread_row<IH, IW, T0, TN, 2>(acc, bh, bl, smem, tbase, rwh, rwl, woff);
+    conv_spread_row<IH, IW, T0, TN, 3>(acc, bh, bl, smem, tbase, rwh, rwl, woff);
+    const float bv = bias[ctile * 16 + m];
+    float mx = 0.f;
+    static_for<TN>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * (T0 + t) + 4 * kg + r;
+            const float v = fmaxf(__builtin_fmaf(acc[t][r], k, bv), 0.f);
+            if (c < G::NC) {
+                dst[c * 128 + ctile * 16 + m] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+    });
+    return mx;
+}
+
+// The block's maximum (non-negative floats compare as their bit patterns) into the board's word.
+__device__ __forceinline__ void conv_spread_block_max(float v, float *s_max, unsigned *__restrict__ word, int lane, int wave) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    if (lane == 0) s_max[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(word, __float_as_uint(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]))));
+}
+
+constexpr size_t conv_spread_lds_bytes() {
+    int a = conv_board_positions(7, 8), b = conv_board_positions(8, 9);
+    return (size_t)(a > b ? a : b) * SP_PB + 64;
+}
+
+__global__ __launch_bounds__(256, 2) void conv_spread_first_kernel(const u64 *__restrict__ side,
+                                                                   const u32x4 *__restrict__ w0h, const u32x4 *__restrict__ w0l,
+                                                                   const float *__restrict__ b0,
+                                                                   const u32x4 *__restrict__ w2h, const u32x4 *__restrict__ w2l,
+                                                                   const float *__restrict__ bias2,
+                                                                   const SplitScales *__restrict__ sc,
+                                                                   float *__restrict__ f32_scratch, unsigned *__restrict__ maxima,
+                                                                   const int32_t *__restrict__ count_ptr, int n_fixed) {
+    using G1 = BoardGeom<7, 8>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *s_max = reinterpret_cast<float *>(smem_raw + conv_spread_lds_bytes() - 64);
+    const int count = batch_count_sp(count_ptr, n_fixed);
+    const int board = blockIdx.x >> 2, cg = blockIdx.x & 3;
+    if (board >= count) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    conv_first_image(smem_raw, side, board, w0h, w0l, b0, sc, tid);
+    __syncthreads();
+    const float k1 = sc->inv_sa1 * sc->inv_sw2;
+    float *dst = f32_scratch + (size_t)board * kSpreadFloatsPerBoard;
+    const int ctile = cg * 2 + (wave >> 1);
+    static_assert(G1::NT == 5, "tiles 0-2 and 3-4");
+    const float mx = (wave & 1) == 0 ? conv_spread_layer<7, 8, 0, 3>(smem_raw, w2h, w2l, bias2, k1, dst, lane, ctile)
+                                     : conv_spread_layer<7, 8, 3, 2>(smem_raw, w2h, w2l, bias2, k1, dst, lane, ctile);
+    conv_spread_block_max(mx, s_max, maxima + 2 * board, lane, wave);
+}
+
+template <bool WRITE_MID>
+__global__ __launch_bounds__(256, 2) void conv_spread_second_kernel(const u32x4 *__restrict__ w4h, const u32x4 *__restrict__ w4l,
+                                                                    const float *__restrict__ bias4,
+                                                                    const SplitScales *__restrict__ sc,
+                                                                    float *__restrict__ f32_scratch, unsigned *__restrict__ maxima,
+                                                                    u32x4 *__restrict__ mid, float *__restrict__ mid_inv_scale,
+                                                                    const int32_t *__restrict__ count_ptr, int n_fixed) {
+    using G2 = BoardGeom<8, 9>;
+    constexpr int IH2 = 8, IW2 = 9, IP2 = 72, W22 = G2::W2, LEAD2 = G2::LEAD, NPOS2 = G2::NPOS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4 *lds = reinterpret_cast<u32x4 *>(smem_raw);
+    float *s_max = reinterpret_cast<float *>(smem_raw + conv_spread_lds_bytes() - 64);
+    const int count = batch_count_sp(count_ptr, n_fixed);
+    const int board = blockIdx.x >> 2, cg = blockIdx.x & 3;
+    if (board >= count) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    float *scratch = f32_scratch + (size_t)board * kSpreadFloatsPerBoard;
+    float sinv;
+    const float sout = pow2_scale(__uint_as_float(maxima[2 * board]), sinv);
+    // the 8x9 image: zeros wherever there is no pixel, the quantised activations where there is one
+    constexpr int TOP = LEAD2, BOT = NPOS2 - (LEAD2 + IH2 * W22), NPAD = TOP + 2 * IH2 + BOT;
+    static_assert(NPAD + IP2 == NPOS2, "every position of the image is a pixel or padding");
+    for (int e = tid; e < NPAD * 32; e += 256) {
+        const int kk = e >> 5, q = e & 31;
+        const int pos = kk < TOP ? kk
+                      : kk < TOP + 2 * IH2 ? LEAD2 + ((kk - TOP) >> 1) * W22 + IW2 + ((kk - TOP) & 1)
+                                           : LEAD2 + IH2 * W22 + (kk - TOP - 2 * IH2);
+        lds[pos * SP_RS + q] = zero4;
+    }
+    {
+        unsigned *ldsw = reinterpret_cast<unsigned *>(smem_raw);
+        const float2 *src = reinterpret_cast<const float2 *>(scratch);
+        for (int e = tid; e < IP2 * 64; e += 256) {              // one channel pair of one pixel
+            const int p = e >> 6, q = e & 63;
+            const float2 v = src[e];
+            _Float16 h0, l0, h1, l1;
+            split_half(v.x * sout, h0, l0);
+            split_half(v.y * sout, h1, l1);
+            const int pos = LEAD2 + (p / IW2) * W22 + p % IW2;
+            ldsw[pos * (SP_PB / 4) + q] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            ldsw[pos * (SP_PB / 4) + SP_LO / 4 + q] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        }
+    }
+    __syncthreads();
+    if constexpr (WRITE_MID) {
+        if (cg == 0) {
+            if (tid == 0) mid_inv_scale[board] = sinv;
+            u32x4 *dstm = mid + (size_t)board * IP2 * 32;
+            for (int e = tid; e < IP2 * 32; e += 256) {
+                const int p = e >> 5, q = e & 31;
+                dstm[e] = lds[(LEAD2 + (p / IW2) * W22 + p % IW2) * SP_RS + q];
+            }
+        }
+    }
+    const float k2 = sinv * sc->inv_sw4;
+    float *dst = scratch + kSpreadMidFloats;
+    const int ctile = cg * 2 + (wave >> 1);
+    static_assert(G2::NT == 6, "tiles 0-2 and 3-5");
+    const float mx = (wave & 1) == 0 ? conv_spread_layer<8, 9, 0, 3>(smem_raw, w4h, w4l, bias4, k2, dst, lane, ctile)
+                                     : conv_spread_layer<8, 9, 3, 3>(smem_raw, w4h, w4l, bias4, k2, dst, lane, ctile);
+    conv_spread_block_max(mx, s_max, maxima + 2 * board + 1, lane, wave);
+}
+
+__global__ __launch_bounds__(256) void conv_spread_pack_kernel(const float *__restrict__ f32_scratch, unsigned *__restrict__ maxima,
+                                                               u32x4 *__restrict__ out, float *__restrict__ out_inv_scale,
+                                                               const int32_t *__restrict__ count_ptr, int n_fixed) {
+    const int count = batch_count_sp(count_ptr, n_fixed);
+    const int board = blockIdx.x, tid = threadIdx.x;
+    if (board >= count) return;
+    float sinv;
+    const float sout = pow2_scale(__uint_as_float(maxima[2 * board + 1]), sinv);
+    const float2 *src = reinterpret_cast<const float2 *>(f32_scratch + (size_t)board * kSpreadFloatsPerBoard + kSpreadMidFloats);
+    unsigned *dst = reinterpret_cast<unsigned *>(out + (size_t)board * 90 * 32);
+    for (int e = tid; e < 90 * 64; e += 256) {
+        const int p = e >> 6, q = e & 63;
+        const float2 v = src[e];
+        _Float16 h0, l0, h1, l1;
+        split_half(v.x * sout, h0, l0);
+        split_half(v.y * sout, h1, l1);
+        dst[p * 128 + q] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+        dst[p * 128 + 64 + q] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+    }
+    __syncthreads();                                             // every thread has its scale: the maxima start the next pass at zero
+    if (tid == 0) { out_inv_scale[board] = sinv; maxima[2 * board] = 0u; maxima[2 * board + 1] = 0u; }
 }
 
 // ---------------------------------------------------------------------------
@@ -836,6 +1095,9 @@ __global__ __launch_bounds__(256, 1) void fc_split_kernel(const u32x4 *__restric
 // through a ring DEPTH k-steps deep.  Every output sums the same products in the same order as in
 // fc_split_kernel (k-steps ascending inside a K half; hi*lo, lo*hi, hi*hi per k-step), so the results are
 // the same bit for bit whatever the batch size.
+#ifndef NNB_FC_SMALL_DEPTH
+#define NNB_FC_SMALL_DEPTH 12
+#endif
 template <int DEPTH>
 __global__ __launch_bounds__(64) void fc_split_small_kernel(const u32x4 *__restrict__ a, const float *__restrict__ a_inv_scale,
                                                             const u32x4 *__restrict__ wph, const u32x4 *__restrict__ wpl,
@@ -956,8 +1218,35 @@ hipError_t prepare_net_kernels_split() {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_board_split_kernel<4, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_board_lds_bytes());
     if (err != hipSuccess) return err;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(conv_board_split_kernel<4, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_board_lds_bytes());
+    err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_board_split_kernel<4, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_board_lds_bytes());
+    if (err != hipSuccess) return err;
+    err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_spread_first_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_spread_lds_bytes());
+    if (err != hipSuccess) return err;
+    err = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_spread_second_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_spread_lds_bytes());
+    if (err != hipSuccess) return err;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(conv_spread_second_kernel<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_spread_lds_bytes());
+}
+
+// The convolutions of at most kSpreadMaxBoards boards, four blocks per board (three launches, see above).
+static void launch_conv_spread(hipStream_t st, const NetWeights &w, const NetBuffers &b, const u64 *side, bool write_mid,
+                               const int32_t *count_ptr, int n_max) {
+    u32x4 *a2 = reinterpret_cast<u32x4 *>(b.act2), *a3 = reinterpret_cast<u32x4 *>(b.act3);
+    conv_spread_first_kernel<<<4 * n_max, 256, conv_spread_lds_bytes(), st>>>(
+        side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
+        (const u32x4 *)w.conv2_wl, w.conv2_b, w.sp_scales, b.spread_f32, b.spread_max, count_ptr, n_max);
+    if (write_mid)
+        conv_spread_second_kernel<true><<<4 * n_max, 256, conv_spread_lds_bytes(), st>>>(
+            (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b, w.sp_scales, b.spread_f32, b.spread_max, a2,
+            b.act2_inv, count_ptr, n_max);
+    else
+        conv_spread_second_kernel<false><<<4 * n_max, 256, conv_spread_lds_bytes(), st>>>(
+            (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b, w.sp_scales, b.spread_f32, b.spread_max, nullptr,
+            nullptr, count_ptr, n_max);
+    conv_spread_pack_kernel<<<n_max, 256, 0, st>>>(b.spread_f32, b.spread_max, a3, b.act3_inv, count_ptr, n_max);
 }
 
 void launch_repack_split(hipStream_t st, const NetWeights &dst, const float *conv0_w, const float *conv0_b,
@@ -986,12 +1275,14 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
     u32x4 *a2 = reinterpret_cast<u32x4 *>(b.act2), *a3 = reinterpret_cast<u32x4 *>(b.act3);
     switch (stage) {
     case NET_CONV_PAIR:         // all three convolutions in one launch; the activations between them stay in LDS
+        if (n_max <= kSpreadMaxBoards && b.spread_f32) { launch_conv_spread(st, w, b, side, false, count_ptr, n_max); break; }
         conv_board_split_kernel<4, false><<<n_max, 256, conv_board_lds_bytes(), st>>>(
             side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
             (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b,
             w.sp_scales, nullptr, nullptr, a3, b.act3_inv, count_ptr, n_max, b.clk);
         break;
     case NET_CONV_PAIR_MID:     // the same, and the 8x9 activations are copied out (nnb_debug_activations)
+        if (n_max <= kSpreadMaxBoards && b.spread_f32) { launch_conv_spread(st, w, b, side, true, count_ptr, n_max); break; }
         conv_board_split_kernel<4, true><<<n_max, 256, conv_board_lds_bytes(), st>>>(
             side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
             (const u32x4 *)w.conv2_wl, w.conv2_b, (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b,
@@ -1001,7 +1292,7 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
         const FcFinish fin = {w.fc_b, w.heads_w, b.fcq, b.write_hidden ? b.fc : nullptr, b.fchand, b.fcsync, b.fcsync + b.fc_pairs,
                               b.sync_err, b.heads_all};
         if (n_max <= kSplitSmallFc) {                            // one wave per 32 rows x 32 columns x K half
-            fc_split_small_kernel<12><<<64 * cdiv_sp(n_max, 32), 64, 0, st>>>(
+            fc_split_small_kernel<NNB_FC_SMALL_DEPTH><<<64 * cdiv_sp(n_max, 32), 64, 0, st>>>(
                 a3, b.act3_inv, (const u32x4 *)w.fc_wh, (const u32x4 *)w.fc_wl, w.sp_scales, fin, count_ptr, n_max,
                 b.max_rows);
             break;

@@ -166,6 +166,13 @@ size_t carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std:
         b.fcsync = c.take<uint32_t>(2 * (size_t)b.fc_pairs);
         b.fcsync_b1 = c.take<uint32_t>(2 * (size_t)b.fc_pairs);
     }
+    // maxima of the four-blocks-per-board convolutions of small batches (zero between passes, so zero at the start)
+    b.spread_max = b.spread_max_b1 = nullptr;
+    b.spread_f32 = b.spread_f32_b1 = nullptr;
+    if (cfg.net_precision == NNB_NET_F32S) {
+        b.spread_max = c.take<uint32_t>(2 * kConvSpreadMaxBoards);
+        b.spread_max_b1 = c.take<uint32_t>(2 * kConvSpreadMaxBoards);
+    }
     b.sync_err = d.counters ? d.counters + kSyncErr : nullptr;
     b.clk = c.take<unsigned long long>(8);              // profiling stamps; kernels get the pointer only while profiling is on
     b.fcq = b.fcq_b1 = b.fchand = b.fchand_b1 = nullptr;
@@ -197,6 +204,9 @@ size_t carve(const nnb_config &cfg, Carver &c, EngineDev &d, NetBuffers &b, std:
         b.fchand_b1 = c.take<float>((G + 128) * 1024);
         b.fcq = c.take<float>(G * 256);
         b.fcq_b1 = c.take<float>(G * 256);
+        const size_t spread_boards = G < (size_t)kConvSpreadMaxBoards ? G : (size_t)kConvSpreadMaxBoards;
+        b.spread_f32 = c.take<float>(spread_boards * kConvSpreadFloatsPerBoard);
+        b.spread_f32_b1 = c.take<float>(spread_boards * kConvSpreadFloatsPerBoard);
         b.act2_b1 = two ? c.take<float>(G * 72 * 128) : nullptr;
         b.act3_b1 = two ? c.take<float>(G * 90 * 128) : nullptr;
         b.act2_inv_b1 = two ? c.take<float>(G) : nullptr;
@@ -357,6 +367,7 @@ NetBuffers batch_buffers(const nnb_engine *e, int batch) {
         b.fcq = b.fcq_b1; b.fchand = b.fchand_b1; b.fcsync = b.fcsync_b1;
         b.act1 = b.act1_b1; b.act2 = b.act2_b1; b.act3 = b.act3_b1;
         b.act2_inv = b.act2_inv_b1; b.act3_inv = b.act3_inv_b1;
+        b.spread_f32 = b.spread_f32_b1; b.spread_max = b.spread_max_b1;
     }
     return b;
 }

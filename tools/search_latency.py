@@ -1,9 +1,13 @@
 import time, torch, numpy as np, sys
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from alphazero_amd.engine import Engine
 from alphazero_amd.network import seeded_state_dict
-for prec in ("f32s", "f16"):
-    for n in (1, 8, 64, 128):
+# usage: search_latency.py [precision[,precision] [roots ...]]
+precs = sys.argv[1].split(",") if len(sys.argv) > 1 else ("f32s", "f16")
+roots = [int(a) for a in sys.argv[2:]] or (1, 8, 64, 128)
+for prec in precs:
+    for n in roots:
         eng = Engine(max_games=n, max_sims=800, precision=prec)
         eng.load_state_dict(seeded_state_dict(0))
         b = np.zeros((n, 2), dtype=np.uint64); p = np.ones(n, dtype=np.int8)
