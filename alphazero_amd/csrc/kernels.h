@@ -106,7 +106,7 @@ enum NetStage { NET_CONV0 = 0, NET_CONV2 = 1, NET_CONV4 = 2, NET_FC = 3, NET_HEA
                 // two 128->128 layers stay in LDS), and the same with those activations also copied out
                 NET_CONV_PAIR = 5, NET_CONV_PAIR_MID = 6 };
 
-constexpr int kConvSpreadMaxBoards = 64;
+constexpr int kConvSpreadMaxBoards = 128;
 constexpr int kConvSpreadFloatsPerBoard = (72 + 90) * 128;
 
 // Ticket / flag words of the linear layer's block pairs for G rows: the large-batch form pairs (row block of 32..128

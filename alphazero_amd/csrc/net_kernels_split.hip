@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void conv_board_split_kernel(const u64 *__r
 }
 
 // ---------------------------------------------------------------------------
-// The same convolutions for a HANDFUL of boards (at most kSpreadMaxBoards: single searches, small tournaments), where
+// The same convolutions for a HANDFUL of boards (at most kSpreadMaxBoards = 128: single searches, small tournaments), where
 // only latency counts: conv_board_split_kernel gives a board to one block, whose four waves each walk 5 or 6 tiles x 2
 // channel tiles through 64 weight steps - about 50 us however few boards there are.  Here FOUR blocks share a board and
 // every wave owns one channel tile of 16 and half of the board's cell tiles, in three launches:

@@ -75,7 +75,7 @@ def test_search_backs_up_the_value_the_network_entry_point_returns(rp):
 @pytest.mark.parametrize("precision", ["f32s", "f16"])
 def test_small_batch_and_large_batch_kernels_agree_bit_for_bit(rp, precision):
     """Small batches run latency-oriented forms of the network kernels: at most 128 positions with half inputs (one
-    board per convolution block), at most 64 float32-faithful positions (four convolution blocks per board, meeting
+    board per convolution block), at most 128 float32-faithful positions (four convolution blocks per board, meeting
     through float32 activations in memory) and at most 256 (one wave per linear-layer block); larger ones the
     throughput forms.  A position's outputs and hidden activations must not depend on which form evaluated it."""
     import torch
@@ -89,7 +89,7 @@ def test_small_batch_and_large_batch_kernels_agree_bit_for_bit(rp, precision):
         legal = eng.game_ops(sb)[1]
         big = eng.net_forward(side, legal)                          # 400 rows: the large-batch kernels
         acts_big = [eng.activations(layer, 100).clone() for layer in (2, 3, 4)]
-        for n in (1, 2, 3, 31, 64, 65, 100, 128, 250):
+        for n in (1, 2, 3, 31, 64, 65, 100, 128, 129, 250):
             small = eng.net_forward(side[:n], legal[:n])            # the small-batch kernels (f16: up to 128 rows)
             for a, b in zip(big, small):
                 assert torch.equal(a[:n], b), n
