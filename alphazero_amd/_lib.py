@@ -78,6 +78,7 @@ SIGNATURES = {
     "nnb_profile_reset": (C.c_int, [_P]),
     "nnb_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "nnb_profile_clocks": (C.c_int, [_P, _P, C.POINTER(C.c_double)]),
+    "nnb_debug_second_stream": (C.c_int, [_P, _P, C.POINTER(C.c_int)]),
 }
 
 _lib = None

@@ -7,6 +7,7 @@
 #include <mutex>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -94,7 +95,10 @@ struct nnb_engine {
     std::vector<int> weights_loaded;
     int32_t *host_counters = nullptr;      // pinned, 16 ints
     unsigned long long *host_stats = nullptr;   // pinned, 8 u64
-    hipStream_t side_stream = nullptr;     // second forward pass of a two-network arena
+    hipStream_t side_stream = nullptr;     // second forward pass of a two-network arena, second chain of a self-play round
+    hipStream_t side_checked_for = nullptr; // the caller's stream that side_stream was last seen to run beside
+    bool side_checked = false;
+    int side_replaced = 0;                  // candidate second streams discarded so far
     hipEvent_t fork_event = nullptr, join_event = nullptr;
     // nnb_selfplay_stream: games stay seated between calls
     bool stream_on = false;
@@ -423,6 +427,68 @@ StepPlan make_step_plan(nnb_engine *e, const nnb_search_params &p, const SearchD
     return plan;
 }
 
+// One wave busy for `ticks` of the 100 MHz clock; the loop is bounded, every wave leaves it.
+__global__ void spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    for (int i = 0; i < (1 << 20) && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(16);
+}
+
+// Do kernels on `a` and `b` run side by side?  HIP spreads a process's streams over a few hardware queues (four by
+// default), and two streams that landed on the same queue run their kernels one after the other however independent
+// they are.  Which queue a new stream gets depends on the streams the process already has (PyTorch's, a collective
+// library's), so it is measured: a 200 us spin on each, the second released by an event of the first.
+bool streams_run_side_by_side(hipStream_t a, hipStream_t b) {
+    constexpr unsigned long long kTicks = 20000;
+    hipEvent_t e0 = nullptr, e1 = nullptr, eb = nullptr;
+    bool ok = true;
+    float ms = 0.f;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&eb) != hipSuccess) ok = false;
+    if (ok) {
+        spin_kernel<<<1, 64, 0, a>>>(0);         // the first launch of a kernel loads its code: not part of the measurement
+        spin_kernel<<<1, 64, 0, b>>>(0);
+        ok = hipStreamSynchronize(b) == hipSuccess;
+        ok = ok && hipEventRecord(e0, a) == hipSuccess && hipStreamWaitEvent(b, e0, 0) == hipSuccess;
+        if (ok) {
+            spin_kernel<<<1, 64, 0, a>>>(kTicks);
+            spin_kernel<<<1, 64, 0, b>>>(kTicks);
+            ok = hipEventRecord(eb, b) == hipSuccess && hipStreamWaitEvent(a, eb, 0) == hipSuccess &&
+                 hipEventRecord(e1, a) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+                 hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (eb) (void)hipEventDestroy(eb);
+    (void)hipGetLastError();
+    return !ok || ms < 0.2f * 1.6f;          // a failed measurement changes nothing
+}
+
+// Before the first pair of chains (or of networks) on the caller's stream `st`: if the engine's second stream shares a
+// hardware queue with it, other streams are created until one does not (the rejected ones are kept until then, so
+// that the next one lands elsewhere).  Nothing of the engine is in flight on the second stream at this point.
+#ifndef NNB_STREAM_PROBE
+#define NNB_STREAM_PROBE 1               // 0: keep whatever stream was created first (timing comparisons only)
+#endif
+void ensure_side_stream(nnb_engine *e, hipStream_t st) {
+    if (!NNB_STREAM_PROBE) return;
+    if (!e->side_stream || (e->side_checked && e->side_checked_for == st)) return;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+    std::vector<hipStream_t> rejected;
+    int tries = 0;
+    for (; tries < 8 && !streams_run_side_by_side(st, e->side_stream); ++tries) {
+        hipStream_t next = nullptr;
+        if (hipStreamCreateWithFlags(&next, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+        rejected.push_back(e->side_stream);
+        e->side_stream = next;
+    }
+    for (hipStream_t s : rejected) (void)hipStreamDestroy(s);
+    if (getenv("NNB_DEBUG_STREAMS")) fprintf(stderr, "nnb: second stream settled after %d replacement(s)\n", tries);
+    e->side_replaced += tries;
+    e->side_checked = true;
+    e->side_checked_for = st;
+}
+
 // One lock-step round: the tree step of every live game, then (unless it is the closing step of a
 // move) the evaluation of the leaves it batched.
 void lockstep_step(nnb_engine *e, hipStream_t st, const nnb_search_params &p, const SearchDev &sd, const StepPlan &plan,
@@ -472,6 +538,7 @@ int run_move(nnb_engine *e, hipStream_t st, const nnb_search_params &p, int32_t 
     const bool fits_lds = lds <= kFusedLdsLimit;
     if (p.evaluator == NNB_EVAL_NET || (p.flags & NNB_FLAG_LOCKSTEP) || (!fits_lds && p.evaluator != NNB_EVAL_ROLLOUT)) {
         const StepPlan plan = make_step_plan(e, p, sd);
+        if (plan.nbatch == 2 && p.evaluator == NNB_EVAL_NET) ensure_side_stream(e, st);
         for (int s = 0; s <= p.sims; ++s) lockstep_step(e, st, p, sd, plan, s & 1, s < p.sims);
         *steps += p.sims;
     } else {
@@ -659,6 +726,7 @@ int run_free_rounds(nnb_engine *e, hipStream_t st, const nnb_search_params &para
                         (slots >= kHalvesMinSlots && e->cfg.net_precision != NNB_NET_F16);
     const bool halves = plan.nbatch == 1 && slots >= 2 * kStepGamesHost && wanted && !(p->flags & NNB_FLAG_ONE_STREAM);
     e->shared_chip = halves;
+    if (halves || (plan.nbatch == 2 && p->evaluator == NNB_EVAL_NET)) ensure_side_stream(e, st);
     if (halves) {
         const int mid = (slots / 2 + kStepGamesHost - 1) / kStepGamesHost * kStepGamesHost;
         const GameSpan span[2] = {{0, mid, 0}, {mid, slots, 1}};
@@ -1195,6 +1263,17 @@ int nnb_profile_clocks(nnb_engine *e, void *stream, double *mhz_out) {
         mhz_out[k] = (c[3] > c[1] && c[2] > c[0]) ? (double)(c[2] - c[0]) / (double)(c[3] - c[1]) * 100.0 : 0.0;
     }
     return NNB_OK;
+}
+
+int nnb_debug_second_stream(nnb_engine *e, void *stream, int *replaced_out) {
+    if (!e) return fail(NNB_ERR_ARG, "engine is null");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    e->side_checked = false;
+    ensure_side_stream(e, st);
+    if (replaced_out) *replaced_out = e->side_replaced;
+    const bool beside = streams_run_side_by_side(st, e->side_stream);
+    HIP_TRY(hipGetLastError());
+    return beside ? 1 : 0;
 }
 
 int nnb_profile_reset(nnb_engine *e) {

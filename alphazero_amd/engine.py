@@ -339,6 +339,16 @@ class Engine:
             check(self.lib.nnb_profile_clocks(self.handle, self._stream(), mhz), "nnb_profile_clocks")
         return {"conv": mhz[0], "fc": mhz[1]}
 
+    def second_stream(self) -> tuple:
+        """(runs beside the current stream, second streams discarded so far): the check every two-chain call makes
+        before its first launch, run now (nnb_debug_second_stream)."""
+        replaced = C.c_int()
+        with torch.cuda.device(self.device):
+            rc = self.lib.nnb_debug_second_stream(self.handle, self._stream(), C.byref(replaced))
+        if rc < 0:
+            check(rc, "nnb_debug_second_stream")
+        return bool(rc), replaced.value
+
     def profile_report(self) -> dict:
         out = {}
         for i, name in enumerate(PROFILE_CLASSES):

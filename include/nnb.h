@@ -391,6 +391,15 @@ int nnb_profile_get(nnb_engine *engine, int which, double *avg_ms_out, int64_t *
  * clock at its start and end while profiling is enabled (float32-faithful path; 0 when nothing was stamped).
  * The matrix peak a roofline is quoted against assumes 2400 MHz.  Synchronous.  No reference counterpart. */
 int nnb_profile_clocks(nnb_engine *engine, void *stream, double *mhz_out);
+/* The engine runs the two chains of a self-play round (and the two networks of an arena) on the caller's stream and
+ * on a second stream of its own.  HIP spreads a process's streams over a few hardware queues, and two streams on one
+ * queue run their kernels one after the other; which queue a stream gets depends on the streams the process already
+ * has (PyTorch's, RCCL's).  Before its first launch on a pair, every such call therefore measures whether the pair
+ * runs side by side (two 200 us spin kernels) and replaces the second stream until it does.  This entry point runs
+ * that check for `stream` now and measures again: returns 1 if the pair runs side by side, 0 if not, negative on
+ * error; *replaced_out (may be null) = second streams discarded since the engine was created.  Synchronous.  No
+ * reference counterpart. */
+int nnb_debug_second_stream(nnb_engine *engine, void *stream, int *replaced_out);
 
 #ifdef __cplusplus
 }

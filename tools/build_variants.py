@@ -20,11 +20,13 @@ VARIANTS = {
     "fcd18": ["-DNNB_FC_SMALL_DEPTH=18"],
     "fcd24": ["-DNNB_FC_SMALL_DEPTH=24"],
     "fcd30": ["-DNNB_FC_SMALL_DEPTH=30"],
+    "noprobe": ["-DNNB_STREAM_PROBE=0"],
     "look32": ["-DNNB_LOOK_ROUNDS=32"],
     "look128": ["-DNNB_LOOK_ROUNDS=128"],
     "look256": ["-DNNB_LOOK_ROUNDS=256"],
 }
 AFFECTED = {"NNB_TERMINAL_SIMS_PER_STEP": ["tree_kernels.hip"], "NNB_LOOK_ROUNDS": ["nnb_api.hip"],
+            "NNB_STREAM_PROBE": ["nnb_api.hip"],
             "NNB_FC_SMALL_DEPTH": ["net_kernels_split.hip"]}
 
 
