@@ -406,11 +406,11 @@ __global__ __launch_bounds__(256, 2) void conv_board_split_kernel(const u64 *__r
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4 *lds = reinterpret_cast<u32x4 *>(smem_raw);
     float *s_max = reinterpret_cast<float *>(smem_raw + REGION);     // [4 waves]
-    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter(); clk[1] = wall_clock64(); }
 
     const int count = batch_count_sp(count_ptr, n_fixed);
     const int board = blockIdx.x;
     if (board >= count) return;
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter(); clk[1] = wall_clock64(); }
     const int tid = threadIdx.x;
     const int lane = tid & 63, nt = tid >> 6;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -621,13 +621,15 @@ __global__ __launch_bounds__(256, 2) void conv_spread_first_kernel(const u64 *__
                                                                    const float *__restrict__ bias2,
                                                                    const SplitScales *__restrict__ sc,
                                                                    float *__restrict__ f32_scratch, unsigned *__restrict__ maxima,
-                                                                   const int32_t *__restrict__ count_ptr, int n_fixed) {
+                                                                   const int32_t *__restrict__ count_ptr, int n_fixed,
+                                                                   unsigned long long *__restrict__ clk) {
     using G1 = BoardGeom<7, 8>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *s_max = reinterpret_cast<float *>(smem_raw + conv_spread_lds_bytes() - 64);
     const int count = batch_count_sp(count_ptr, n_fixed);
     const int board = blockIdx.x >> 2, cg = blockIdx.x & 3;
     if (board >= count) return;
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter(); clk[1] = wall_clock64(); }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     conv_first_image(smem_raw, side, board, w0h, w0l, b0, sc, tid);
     __syncthreads();
@@ -638,6 +640,7 @@ __global__ __launch_bounds__(256, 2) void conv_spread_first_kernel(const u64 *__
     const float mx = (wave & 1) == 0 ? conv_spread_layer<7, 8, 0, 3>(smem_raw, w2h, w2l, bias2, k1, dst, lane, ctile)
                                      : conv_spread_layer<7, 8, 3, 2>(smem_raw, w2h, w2l, bias2, k1, dst, lane, ctile);
     conv_spread_block_max(mx, s_max, maxima + 2 * board, lane, wave);
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[2] = __builtin_readcyclecounter(); clk[3] = wall_clock64(); }
 }
 
 template <bool WRITE_MID>
@@ -1102,11 +1105,13 @@ template <int DEPTH>
 __global__ __launch_bounds__(64) void fc_split_small_kernel(const u32x4 *__restrict__ a, const float *__restrict__ a_inv_scale,
                                                             const u32x4 *__restrict__ wph, const u32x4 *__restrict__ wpl,
                                                             const SplitScales *__restrict__ sc, FcFinish fin,
-                                                            const int32_t *__restrict__ count_ptr, int n_fixed, int max_rows) {
+                                                            const int32_t *__restrict__ count_ptr, int n_fixed, int max_rows,
+                                                            unsigned long long *__restrict__ clk) {
     const int count = batch_count_sp(count_ptr, n_fixed);
     const int bid = blockIdx.x, rt = bid >> 6, ct = (bid >> 1) & 31, ksp = bid & 1;
     const int row0 = rt * 32;
     if (row0 >= count) return;
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter(); clk[1] = wall_clock64(); }
     const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
     constexpr int KHALF = FCS_K / FCS_SPLIT, NKS = KHALF / 16;           // 360 k-steps of 16
     // the resource starts at this block's first row (64-bit arithmetic), so 32-bit offsets stay inside 32 rows
@@ -1160,6 +1165,7 @@ __global__ __launch_bounds__(64) void fc_split_small_kernel(const u32x4 *__restr
     ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
     f32x16 tile[1] = {acc};
     fc_split_finish<1, 1, 1>(tile, fin, a_inv_scale, sc->inv_swf, ticket, pair, (size_t)pair * 1024, row0, count, max_rows, ct, 0, lane);
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[2] = __builtin_readcyclecounter(); clk[3] = wall_clock64(); }
 }
 
 // The heads from the linear layer's per-tile partial sums (heads_math.h: heads_z_from_q), then log-softmax, tanh and
@@ -1237,7 +1243,7 @@ static void launch_conv_spread(hipStream_t st, const NetWeights &w, const NetBuf
     u32x4 *a2 = reinterpret_cast<u32x4 *>(b.act2), *a3 = reinterpret_cast<u32x4 *>(b.act3);
     conv_spread_first_kernel<<<4 * n_max, 256, conv_spread_lds_bytes(), st>>>(
         side, (const u32x4 *)w.conv0_wh, (const u32x4 *)w.conv0_wl, w.conv0_b, (const u32x4 *)w.conv2_wh,
-        (const u32x4 *)w.conv2_wl, w.conv2_b, w.sp_scales, b.spread_f32, b.spread_max, count_ptr, n_max);
+        (const u32x4 *)w.conv2_wl, w.conv2_b, w.sp_scales, b.spread_f32, b.spread_max, count_ptr, n_max, b.clk);
     if (write_mid)
         conv_spread_second_kernel<true><<<4 * n_max, 256, conv_spread_lds_bytes(), st>>>(
             (const u32x4 *)w.conv4_wh, (const u32x4 *)w.conv4_wl, w.conv4_b, w.sp_scales, b.spread_f32, b.spread_max, a2,
@@ -1294,7 +1300,7 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
         if (n_max <= kSplitSmallFc) {                            // one wave per 32 rows x 32 columns x K half
             fc_split_small_kernel<NNB_FC_SMALL_DEPTH><<<64 * cdiv_sp(n_max, 32), 64, 0, st>>>(
                 a3, b.act3_inv, (const u32x4 *)w.fc_wh, (const u32x4 *)w.fc_wl, w.sp_scales, fin, count_ptr, n_max,
-                b.max_rows);
+                b.max_rows, b.clk ? b.clk + 4 : nullptr);
             break;
         }
         const int groups = cdiv_sp(cdiv_sp(n_max, 128), 32);       // 32 row blocks per group of 256 blocks

@@ -17,5 +17,6 @@ for prec in precs:
         torch.cuda.synchronize(); t0 = time.perf_counter()
         eng.search(b, p, prm)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(prec, n, "roots x 800 sims: %.1f ms" % (dt * 1e3), {k: round(v["avg_ms"] * 1e3, 1) for k, v in eng.profile_report().items() if v["avg_ms"] > 0}, flush=True)
+        print(prec, n, "roots x 800 sims: %.1f ms" % (dt * 1e3), {k: round(v["avg_ms"] * 1e3, 1) for k, v in eng.profile_report().items() if v["avg_ms"] > 0},
+              {k: round(v) for k, v in eng.profile_clocks().items()} if prec == "f32s" else "", flush=True)
         eng.close()
