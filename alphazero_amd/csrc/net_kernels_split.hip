@@ -1217,7 +1217,10 @@ static inline int cdiv_sp(int a, int b) { return (a + b - 1) / b; }
 
 // Up to this many rows the linear layer runs its latency-oriented form (one wave per block); the convolution kernel
 // is one board per block at every batch size.  Whole forward passes: tools/net_latency.py.
-constexpr int kSplitSmallFc = 256;
+#ifndef NNB_FC_SMALL_ROWS
+#define NNB_FC_SMALL_ROWS 256
+#endif
+constexpr int kSplitSmallFc = NNB_FC_SMALL_ROWS;
 static_assert(2 * conv_board_lds_bytes() <= 160 * 1024, "two blocks of the convolution kernel share a CU");
 
 hipError_t prepare_net_kernels_split() {

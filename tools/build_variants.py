@@ -20,13 +20,15 @@ VARIANTS = {
     "fcd18": ["-DNNB_FC_SMALL_DEPTH=18"],
     "fcd24": ["-DNNB_FC_SMALL_DEPTH=24"],
     "fcd30": ["-DNNB_FC_SMALL_DEPTH=30"],
+    "fcs64": ["-DNNB_FC_SMALL_ROWS=64"],
+    "fcs128": ["-DNNB_FC_SMALL_ROWS=128"],
     "noprobe": ["-DNNB_STREAM_PROBE=0"],
     "look32": ["-DNNB_LOOK_ROUNDS=32"],
     "look128": ["-DNNB_LOOK_ROUNDS=128"],
     "look256": ["-DNNB_LOOK_ROUNDS=256"],
 }
 AFFECTED = {"NNB_TERMINAL_SIMS_PER_STEP": ["tree_kernels.hip"], "NNB_LOOK_ROUNDS": ["nnb_api.hip"],
-            "NNB_STREAM_PROBE": ["nnb_api.hip"],
+            "NNB_STREAM_PROBE": ["nnb_api.hip"], "NNB_FC_SMALL_ROWS": ["net_kernels_split.hip"],
             "NNB_FC_SMALL_DEPTH": ["net_kernels_split.hip"]}
 
 
