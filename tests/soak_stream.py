@@ -1,6 +1,6 @@
-"""Soak run of the benchmark's workload: a long stream of self-play games (4096 slots, 200 sims/move, network,
+"""Not collected by pytest (a long run, started by hand): soak run of the benchmark's workload: a long stream of self-play games (4096 slots, 200 sims/move, network,
 float32-faithful, two chains), every finished record replayed against the rule oracle, duplicates of one start
-position compared byte for byte, and a sample re-played as a plain round.  Usage: python tools/soak_stream.py [steps]"""
+position compared byte for byte, and a sample re-played as a plain round.  Usage: python tests/soak_stream.py [steps]"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
