@@ -107,12 +107,13 @@ def test_arena_rejects_unknown_or_unloaded_sets(arena_engine):
         eng.selfplay_round(4, eng.params(10, 1.4, evaluator="net", weight_set=0, weight_set_colour2=1))
 
 
-@pytest.mark.parametrize("precision", ["f16", "f32"])
+@pytest.mark.parametrize("precision", ["f16", "f32", "f32s"])
 def test_arena_two_networks(oracle, precision):
     """Both networks batched on the device.  (a) The same weights loaded as sets 0 and 1 must
     replay single-set self-play byte for byte although the leaves now travel in two batches;
     (b) seeds 0 and 1 against each other follow the CPU game, move for move on the float32
-    path and at least through the opening with half inputs (a near tie may flip there)."""
+    and float32-faithful paths (the latter: two small batches, whose convolutions run four blocks per board on two
+    streams with a scratch area each) and at least through the opening with half inputs (a near tie may flip there)."""
     from alphazero_amd.engine import Engine, trajectories_to_numpy
     co, rp = oracle
     sd0, sd1 = rp.seeded_state_dict(0), rp.seeded_state_dict(1)
@@ -146,7 +147,7 @@ def test_arena_two_networks(oracle, precision):
             for i in range(s - 1, n, 2):
                 r = rec[i]
                 got = r["plies"]["action"][:r["length"]].tolist()
-                if precision == "f32":
+                if precision in ("f32", "f32s"):
                     assert got == moves and r["result"] == res
                     assert r["plies"]["visits"][:len(moves)].tolist() == visits
                 else:
