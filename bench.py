@@ -141,8 +141,8 @@ def committed_traffic(precision: str, kernel: str, leaves_per_launch: float):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--games", type=int, default=GAMES_PER_GPU, help="concurrent games (slots) per GPU")
     ap.add_argument("--games-per-step", type=int, default=0,
                     help="finished games per GPU a step waits for (default: --games)")
