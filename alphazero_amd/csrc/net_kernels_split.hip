@@ -780,19 +780,38 @@ struct FcFinish {
     int heads_all;              // 0: the value head only
 };
 
+// Value of lane ^ K for K = 1, 2, 4, 8, in the vector pipe (DPP): quad permutes, a rotation by 8 within a row of 16
+// lanes, and for K = 4 a shift left into lane groups 0 and 2 of a row plus a shift right into groups 1 and 3.
 template <int K>
-__device__ __forceinline__ float lane_xor(float v) {                 // value of lane ^ K, K < 32 (no memory access)
-    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (K << 10) | 0x1F));
+__device__ __forceinline__ float lane_xor(float v) {
+    const int x = __float_as_int(v);
+    int r;
+    if constexpr (K == 1) r = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);             // quad_perm [1,0,3,2]
+    else if constexpr (K == 2) r = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);        // quad_perm [2,3,0,1]
+    else if constexpr (K == 4) {
+        r = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xF, 0x5, false);                       // row_shl:4 -> groups 0, 2
+        r = __builtin_amdgcn_update_dpp(r, x, 0x114, 0xF, 0xA, false);                       // row_shr:4 -> groups 1, 3
+    } else {
+        static_assert(K == 8, "lane distances 1, 2, 4 and 8");
+        r = __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false);                       // row_ror:8
+    }
+    return __int_as_float(r);
 }
 
 // p[r], r = 0..15: this lane's column of an MFMA tile's 16 rows.  Returns the sum over the 32 columns (lanes of
 // this half wave) of ONE of those rows: r = 8*bit4(m) + 4*bit3(m) + 2*bit2(m) + bit1(m).  Each exchange halves the
-// values a lane carries, so 16 exchanges do what 80 would do by reducing every row in every lane.
+// values a lane carries, so 16 exchanges do what 80 would do by reducing every row in every lane.  The first level
+// (lanes 16 apart) is v_permlane16_swap: it trades the odd 16-lane rows of p[i] for the even rows of p[8 + i], after
+// which every lane holds its own value and its partner's for the row it keeps (a + b = b + a bit for bit, so which of
+// the two arrived does not matter).  tools/lane_exchange_check.hip checks all five exchanges on the device.
 __device__ __forceinline__ float tile_column_sum(const float (&p)[16], int m) {
     float v8[8], v4[4], v2[2];
-    const bool b4 = m & 16, b3 = m & 8, b2 = m & 4, b1 = m & 2;
+    const bool b3 = m & 8, b2 = m & 4, b1 = m & 2;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v8[i] = (b4 ? p[8 + i] : p[i]) + lane_xor<16>(b4 ? p[i] : p[8 + i]);
+    for (int i = 0; i < 8; ++i) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p[i]), __float_as_uint(p[8 + i]), false, false);
+        v8[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) v4[i] = (b3 ? v8[4 + i] : v8[i]) + lane_xor<8>(b3 ? v8[i] : v8[4 + i]);
 #pragma unroll
