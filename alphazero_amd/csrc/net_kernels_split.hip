@@ -141,12 +141,12 @@ constexpr size_t conv_board_lds_bytes() {
 // ---------------------------------------------------------------------------
 // All three convolutions, ONE board per block, 16-cell tiles (conv_board_split_kernel).
 //
-// The board's output cells are taken row-major, 16 at a time, as the rows of v_mfma_f32_16x16x32_f16 tiles: 72 cells
-// = 5 tiles for the 7x8 -> 8x9 layer, 90 cells = 6 tiles for 8x9 -> 9x10 (a 32-row tile of one board would waste a
-// quarter of the last one; one output row of three boards fills 27 and 30 of 32 rows, but three boards' images take
-// 145 KB of LDS: one block per CU, one wave per SIMD, nothing to run under the 18 % of a block's cycles that are not
-// matrix work - measured 724 us against 637 us per 3979 boards).  A tile spans at most three
-// output rows, so the (tile, kernel row) pairs that read nothing but padding are still known at compile time and
+// The board's output cells are the rows of v_mfma_f32_16x16x32_f16 tiles, 16 at a time: 72 cells = 5 tiles for the
+// 7x8 -> 8x9 layer, 90 cells = 6 tiles for 8x9 -> 9x10 (a 32-row tile of one board would waste a quarter of the last
+// one; one output row of three boards fills 27 and 30 of 32 rows, but three boards' images take 145 KB of LDS: one
+// block per CU, one wave per SIMD, nothing to run under the 18 % of a block's cycles that are not matrix work -
+// measured 724 us against 637 us per 3979 boards).  Which cells share a tile is BoardTiles' business: cells on the
+// same border share the taps that read only padding, and those (tile, tap) pairs are known at compile time and
 // skipped.  The image of one board takes 72 KB of LDS and a wave at most 256 registers, so TWO blocks share a CU:
 // while one is in its prologue or one of its epilogues (no matrix work), the other one's waves keep the matrix pipe
 // busy - on a power-capped chip more pipes busy at a lower clock deliver more than fewer at a higher one.  The price
@@ -168,20 +168,59 @@ struct BoardGeom {
     static constexpr bool live(int t, int kh) { return row_last(t) + kh - 2 >= 0 && row_first(t) + kh - 2 < IH; }
 };
 
-// All four taps of kernel row KH for the live tiles.  Fragments of one (tap, k-step) are read one step ahead into the
+// Which output cells share a 16-row tile in conv_board_split_kernel.  A tile pays for a tap as soon as ONE of its cells
+// reads a pixel through it, so cells are grouped by the taps that fall on the zero border for all of them:
+//   7x8 -> 8x9   tile 0 = output column 0 (8 cells: kernel columns 0 and 1 read only padding), tiles 1-4 = two output
+//                rows x columns 1-8 (rows 0-1 skip kernel row 0, rows 6-7 kernel row 3): 64 (tile, tap) pairs of 80
+//   8x9 -> 9x10  tile 0 = output row 0 (10 cells: kernel rows 0 and 1 read only padding), tiles 1-5 = two output
+//                columns x rows 1-8 (columns 0-1 skip kernel column 0, columns 8-9 kernel column 3): 80 of 96
+// against 68 and 84 with the cells taken row-major.  A skipped tap multiplies zeros, so every accumulator still sums
+// the same products in the same order as with any other grouping (conv_spread_* keep the row-major one).
+template <int IH, int IW>
+struct BoardTiles {
+    static constexpr int OH = IH + 1, OW = IW + 1, NC = OH * OW, W2 = IW + 2, LEAD = 2 + 2 * W2;
+    static constexpr bool ROWS = OW == 9;                        // row-pair tiles (8 columns wide), else column-pair tiles
+    static_assert(ROWS ? OH % 2 == 0 : (OH == 9 && OW % 2 == 0), "the two layers of this network");
+    static constexpr int NT = 1 + (ROWS ? OH / 2 : OW / 2);
+    static constexpr int cells(int t) { return t > 0 ? 16 : ROWS ? OH : OW; }
+    // output row and column of cell i < cells(t) of tile t
+    static constexpr int row(int t, int i) { return ROWS ? (t == 0 ? i : 2 * (t - 1) + (i >> 3)) : (t == 0 ? 0 : 1 + (i >> 1)); }
+    static constexpr int col(int t, int i) { return ROWS ? (t == 0 ? 0 : 1 + (i & 7)) : (t == 0 ? i : 2 * (t - 1) + (i & 1)); }
+    static constexpr int row_first(int t) { return row(t, 0); }
+    static constexpr int row_last(int t) { return row(t, cells(t) - 1); }
+    static constexpr int col_first(int t) { return col(t, 0); }
+    static constexpr int col_last(int t) { return ROWS ? (t == 0 ? 0 : 8) : (t == 0 ? OW - 1 : 2 * t - 1); }
+    // kernel row kh / kernel column kw of tile t reads at least one pixel
+    static constexpr bool live_kh(int t, int kh) { return row_last(t) + kh - 2 >= 0 && row_first(t) + kh - 2 < IH; }
+    static constexpr bool live_kw(int t, int kw) { return col_last(t) + kw - 2 >= 0 && col_first(t) + kw - 2 < IW; }
+    static constexpr int kw_first(int t) { return live_kw(t, 0) ? 0 : live_kw(t, 1) ? 1 : 2; }    // the live ones are contiguous
+    static constexpr int kw_last(int t) { return live_kw(t, 3) ? 3 : live_kw(t, 2) ? 2 : 1; }
+    static constexpr bool every_kw(int t) { return kw_first(t) == 0 && kw_last(t) == 3; }
+    static constexpr int pairs() {
+        int n = 0;
+        for (int t = 0; t < NT; ++t)
+            for (int k = 0; k < 16; ++k) n += live_kh(t, k >> 2) && live_kw(t, k & 3);
+        return n;
+    }
+};
+static_assert(BoardTiles<7, 8>::NT == 5 && BoardTiles<7, 8>::pairs() == 64, "7x8 -> 8x9");
+static_assert(BoardTiles<8, 9>::NT == 6 && BoardTiles<8, 9>::pairs() == 80, "8x9 -> 9x10");
+
+// All four taps of kernel row KH for the live tiles (a tile whose cells all sit in a border column skips the kernel
+// columns that read nothing but padding: one uniform branch per k-step).  Fragments of one (tap, k-step) are read one step ahead into the
 // other of two register sets; weights BRING - 1 steps ahead.  acc[t][j]: tile t, channel tile j.
 template <int IH, int IW, int NT, int BRING, int KH>
 __device__ __forceinline__ void conv_board_row(f32x4 (&acc)[NT][2], u32x4 (&bh)[BRING][2], u32x4 (&bl)[BRING][2],
                                                const unsigned char *smem, const int (&tbase)[NT],
                                                const __amdgpu_buffer_rsrc_t &rwh, const __amdgpu_buffer_rsrc_t &rwl, int woff) {
-    using G = BoardGeom<IH, IW>;
+    using G = BoardTiles<IH, IW>;
     static_assert(NT == G::NT, "one accumulator pair per tile");
     constexpr int W2 = G::W2, PB = SP_PB;
     u32x4 ah[2][NT], al[2][NT];
     const unsigned char *p0 = smem + ((KH - 2) * W2 - 2) * PB;
     static_for<NT>([&](auto T) __attribute__((always_inline)) {
         constexpr int t = decltype(T)::value;
-        if constexpr (G::live(t, KH)) {
+        if constexpr (G::live_kh(t, KH)) {
             ah[0][t] = *reinterpret_cast<const u32x4 *>(p0 + tbase[t]);
             al[0][t] = *reinterpret_cast<const u32x4 *>(p0 + tbase[t] + SP_LO);
         }
@@ -207,7 +246,7 @@ __device__ __forceinline__ void conv_board_row(f32x4 (&acc)[NT][2], u32x4 (&bh)[
 #endif
             static_for<NT>([&](auto T) __attribute__((always_inline)) {       // fragments of the next step
                 constexpr int t = decltype(T)::value;
-                if constexpr (G::live(t, KH)) {
+                if constexpr (G::live_kh(t, KH)) {
                     if constexpr (ks < 3) {
                         ah[nxt][t] = *reinterpret_cast<const u32x4 *>(pv + tbase[t] + (ks + 1) * 64);
                         al[nxt][t] = *reinterpret_cast<const u32x4 *>(pv + tbase[t] + (ks + 1) * 64 + SP_LO);
@@ -221,7 +260,7 @@ __device__ __forceinline__ void conv_board_row(f32x4 (&acc)[NT][2], u32x4 (&bh)[
             const half8 wl0 = as_half8(bl[slot][0]), wl1 = as_half8(bl[slot][1]);
             static_for<NT>([&](auto T) __attribute__((always_inline)) {
                 constexpr int t = decltype(T)::value;
-                if constexpr (G::live(t, KH)) {
+                if (G::live_kh(t, KH) && (G::every_kw(t) || (kw >= G::kw_first(t) && kw <= G::kw_last(t)))) {
                     const half8 xh = as_half8(ah[cur][t]), xl = as_half8(al[cur][t]);
                     // per accumulator: hi*lo, lo*hi, hi*hi, in this order; the two channel tiles alternate
                     acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl0, acc[t][0], 0, 0, 0);
@@ -240,15 +279,14 @@ __device__ __forceinline__ void conv_board_row(f32x4 (&acc)[NT][2], u32x4 (&bh)[
 template <int IH, int IW, int NT, int BRING>
 __device__ __forceinline__ void conv_board_layer(f32x4 (&acc)[NT][2], const unsigned char *smem,
                                                  const u32x4 *wph, const u32x4 *wpl, int lane, int wave) {
-    using G = BoardGeom<IH, IW>;
+    using G = BoardTiles<IH, IW>;
     static_assert(NT == G::NT, "one accumulator pair per tile");
     const int m = lane & 15, kg = lane >> 4;
     int tbase[G::NT];
     static_for<G::NT>([&](auto T) __attribute__((always_inline)) {
         constexpr int t = decltype(T)::value;
-        int c = 16 * t + m;
-        c = c < G::NC ? c : G::NC - 1;                           // rows past the last cell repeat it
-        tbase[t] = (G::LEAD + (c / G::OW) * G::W2 + c % G::OW) * SP_PB + kg * 16;
+        const int i = m < G::cells(t) ? m : G::cells(t) - 1;     // rows past the tile's last cell repeat it
+        tbase[t] = (G::LEAD + G::row(t, i) * G::W2 + G::col(t, i)) * SP_PB + kg * 16;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { acc[t][0][r] = 0.f; acc[t][1][r] = 0.f; }
     });
@@ -269,14 +307,14 @@ __device__ __forceinline__ void conv_board_layer(f32x4 (&acc)[NT][2], const unsi
 }
 
 // v = ReLU(acc * k + bias) in place; returns this lane's maximum over the board's cells
-template <int NT, int NC>
-__device__ __forceinline__ float conv_board_finish(f32x4 (&acc)[NT][2], float k, const float (&bv)[2], int kg) {
+template <typename G>
+__device__ __forceinline__ float conv_board_finish(f32x4 (&acc)[G::NT][2], float k, const float (&bv)[2], int kg) {
     float mx = 0.f;
-    static_for<NT>([&](auto T) __attribute__((always_inline)) {
+    static_for<G::NT>([&](auto T) __attribute__((always_inline)) {
         constexpr int t = decltype(T)::value;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool valid = 16 * t + 15 < NC || 16 * t + 4 * kg + r < NC;
+            const bool valid = G::cells(t) == 16 || 4 * kg + r < G::cells(t);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float v = fmaxf(__builtin_fmaf(acc[t][j][r], k, bv[j]), 0.f);
@@ -288,19 +326,19 @@ __device__ __forceinline__ float conv_board_finish(f32x4 (&acc)[NT][2], float k,
     return mx;
 }
 
-// Quantised with the board's scale, hi / lo into LDS: output cell c = (row, column) goes to position
+// Quantised with the board's scale, hi / lo into LDS: the output cell at (row, column) goes to position
 // LEADO + row * RSO + column.  A lane swaps its (hi, lo) pair with the neighbouring channel's lane (same cell): the
 // even lane stores both hi halves, the odd lane both lo halves, one 32-bit word each (as conv_split_store).
-template <int NT, int NC, int OW, int RSO, int LEADO>
-__device__ __forceinline__ void conv_board_store(const f32x4 (&acc)[NT][2], float sc_out, unsigned *ldsw, int wave, int lane) {
+template <typename G, int RSO, int LEADO>
+__device__ __forceinline__ void conv_board_store(const f32x4 (&acc)[G::NT][2], float sc_out, unsigned *ldsw, int wave, int lane) {
     const int m = lane & 15, kg = lane >> 4, odd = lane & 1;
     const unsigned psel = odd ? 0x03020706u : 0x05040100u;
-    static_for<NT>([&](auto T) __attribute__((always_inline)) {
+    static_for<G::NT>([&](auto T) __attribute__((always_inline)) {
         constexpr int t = decltype(T)::value;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int c = 16 * t + 4 * kg + r;
-            const int pos = LEADO + (c / OW) * RSO + c % OW;
+            const int i = 4 * kg + r;
+            const int pos = LEADO + G::row(t, i) * RSO + G::col(t, i);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
@@ -311,7 +349,7 @@ __device__ __forceinline__ void conv_board_store(const f32x4 (&acc)[NT][2], floa
                 const unsigned own = __builtin_bit_cast(unsigned, pr);
                 const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);   // lane ^ 1
                 const int ch = wave * 32 + 16 * j + m;
-                if (16 * t + 15 < NC || c < NC)
+                if (G::cells(t) == 16 || i < G::cells(t))
                     ldsw[pos * (SP_PB / 4) + (ch >> 1) + (odd ? SP_LO / 4 : 0)] = __builtin_amdgcn_perm(other, own, psel);
             }
         }
@@ -396,11 +434,11 @@ __global__ __launch_bounds__(256, 2) void conv_board_split_kernel(const u64 *__r
                                                                   u32x4 *__restrict__ out, float *__restrict__ out_inv_scale,
                                                                   const int32_t *__restrict__ count_ptr, int n_fixed,
                                                                   unsigned long long *__restrict__ clk) {
-    using G1 = BoardGeom<7, 8>;
-    using G2 = BoardGeom<8, 9>;
+    using G1 = BoardTiles<7, 8>;
+    using G2 = BoardTiles<8, 9>;
     constexpr int PB = SP_PB;
-    constexpr int NPOS1 = G1::NPOS;
-    constexpr int IH2 = 8, IW2 = 9, IP2 = 72, W22 = G2::W2, LEAD2 = G2::LEAD, NPOS2 = G2::NPOS;
+    constexpr int NPOS1 = BoardGeom<7, 8>::NPOS;
+    constexpr int IH2 = 8, IW2 = 9, IP2 = 72, W22 = G2::W2, LEAD2 = G2::LEAD, NPOS2 = BoardGeom<8, 9>::NPOS;
     constexpr int OP2 = G2::NC;
     constexpr int REGION = (NPOS2 > NPOS1 ? (NPOS2 > OP2 ? NPOS2 : OP2) : (NPOS1 > OP2 ? NPOS1 : OP2)) * PB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -429,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void conv_board_split_kernel(const u64 *__r
         NNB_SP_STAMP(2)
         const float k1 = sc->inv_sa1 * sc->inv_sw2;
         const float bv[2] = {bias2[nt * 32 + m16], bias2[nt * 32 + 16 + m16]};
-        float v = conv_board_finish<G1::NT, G1::NC>(acc, k1, bv, kg);
+        float v = conv_board_finish<G1>(acc, k1, bv, kg);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
         if (lane == 0) s_max[nt] = v;
@@ -446,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void conv_board_split_kernel(const u64 *__r
                                                : LEAD2 + IH2 * W22 + (kk - TOP - 2 * IH2);
             lds[pos * SP_RS + q] = zero4;
         }
-        conv_board_store<G1::NT, G1::NC, G1::OW, W22, LEAD2>(acc, sout, reinterpret_cast<unsigned *>(smem_raw), nt, lane);
+        conv_board_store<G1, W22, LEAD2>(acc, sout, reinterpret_cast<unsigned *>(smem_raw), nt, lane);
         k2 = sinv * sc->inv_sw4;
         if constexpr (WRITE_MID) {
             if (tid == 0) mid_inv_scale[board] = sinv;
@@ -467,14 +505,14 @@ __global__ __launch_bounds__(256, 2) void conv_board_split_kernel(const u64 *__r
     conv_board_layer<8, 9, G2::NT, BRING>(acc, smem_raw, w4h, w4l, lane, nt);
     NNB_SP_STAMP(7)
     const float bv[2] = {bias4[nt * 32 + m16], bias4[nt * 32 + 16 + m16]};
-    float v = conv_board_finish<G2::NT, G2::NC>(acc, k2, bv, kg);
+    float v = conv_board_finish<G2>(acc, k2, bv, kg);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
     if (lane == 0) s_max[nt] = v;
     __syncthreads();                                             // every wave is done with the second image
     float sinv;
     const float sout = pow2_scale(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])), sinv);
-    conv_board_store<G2::NT, G2::NC, G2::OW, G2::OW, 0>(acc, sout, reinterpret_cast<unsigned *>(smem_raw), nt, lane);
+    conv_board_store<G2, G2::OW, 0>(acc, sout, reinterpret_cast<unsigned *>(smem_raw), nt, lane);
     __syncthreads();
     u32x4 *dst = out + (size_t)board * OP2 * 32;
     for (int e = tid; e < OP2 * 32; e += 256) dst[e] = lds[(e >> 5) * SP_RS + (e & 31)];
