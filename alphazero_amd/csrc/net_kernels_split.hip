@@ -202,9 +202,26 @@ struct BoardTiles {
             for (int k = 0; k < 16; ++k) n += live_kh(t, k >> 2) && live_kw(t, k & 3);
         return n;
     }
+    // every output cell sits in exactly one tile, and no tap a cell needs is skipped for its tile
+    static constexpr bool sound() {
+        int seen[OH * OW] = {};
+        for (int t = 0; t < NT; ++t)
+            for (int i = 0; i < cells(t); ++i) {
+                const int y = row(t, i), x = col(t, i);
+                if (y < 0 || y >= OH || x < 0 || x >= OW) return false;
+                ++seen[y * OW + x];
+                for (int k = 0; k < 16; ++k) {
+                    const bool reads_pixel = y + (k >> 2) - 2 >= 0 && y + (k >> 2) - 2 < IH && x + (k & 3) - 2 >= 0 && x + (k & 3) - 2 < IW;
+                    if (reads_pixel && !(live_kh(t, k >> 2) && live_kw(t, k & 3))) return false;
+                }
+            }
+        for (int c = 0; c < OH * OW; ++c)
+            if (seen[c] != 1) return false;
+        return true;
+    }
 };
-static_assert(BoardTiles<7, 8>::NT == 5 && BoardTiles<7, 8>::pairs() == 64, "7x8 -> 8x9");
-static_assert(BoardTiles<8, 9>::NT == 6 && BoardTiles<8, 9>::pairs() == 80, "8x9 -> 9x10");
+static_assert(BoardTiles<7, 8>::NT == 5 && BoardTiles<7, 8>::pairs() == 64 && BoardTiles<7, 8>::sound(), "7x8 -> 8x9");
+static_assert(BoardTiles<8, 9>::NT == 6 && BoardTiles<8, 9>::pairs() == 80 && BoardTiles<8, 9>::sound(), "8x9 -> 9x10");
 
 // All four taps of kernel row KH for the live tiles (a tile whose cells all sit in a border column skips the kernel
 // columns that read nothing but padding: one uniform branch per k-step).  Fragments of one (tap, k-step) are read one step ahead into the
