@@ -69,6 +69,9 @@ PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f32s": 2500.0}
 DTYPE_NAME = {"f16": "f16 (f32 accumulate)", "f32": "f32",
               "f32s": "f32 (each operand a hi+lo pair of halves, 3 half-input MFMAs per product, f32 accumulate)"}
 PEAK_HBM_GBS = 8000.0
+# What the matrix pipes of one box deliver from registers with changing operands and nothing else running: the socket's
+# power cap holds the clock at 1.62 GHz (tools/mfma_peak, profiles/r03_mfma_power_ceiling.txt).  Reported beside `peak`.
+POWER_CAPPED_MFMA_TFLOPS = 1630.0
 KERNEL_NAME = {}
 
 
@@ -382,6 +385,21 @@ def main():
         sims_per_launch = totals["sims"] / steps_launched
         tree_gbs = (sims_per_launch * tree_bytes_per_sim) / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
         mfma_per_product = 3 if args.precision == "f32s" else 1
+        # FLOPs of the matrix instructions the kernel issues per leaf: three per product on the float32-faithful path,
+        # minus, in its convolutions, the (tile, tap) pairs on the zero border that are skipped (4 waves x 3456
+        # 16x16x32 instructions per board + the 2->128 layer), which the algorithmic count includes
+        issued_flop = {k: v * mfma_per_product for k, v in FLOP_PER_LEAF.items()}
+        if args.precision == "f32s":
+            issued_flop["conv2"] = 4 * 3456 * 16384 + 4 * 8 * 32768
+
+        def issued(tflops_algorithmic):
+            t = tflops_algorithmic * issued_flop[dom] / FLOP_PER_LEAF[dom]
+            return {"issued_tflops": t, "issued_frac": t / PEAK_TFLOPS[args.precision],
+                    "issued_flop_per_leaf": issued_flop[dom],
+                    "power_capped_ceiling": {"tflops": POWER_CAPPED_MFMA_TFLOPS, "frac": t / POWER_CAPPED_MFMA_TFLOPS,
+                                             "source": "profiles/r03_mfma_power_ceiling.txt: what the matrix pipes of one "
+                                                       "box deliver from registers with changing operands and nothing "
+                                                       "else running (1400 W cap, 1.62 GHz); `peak` is the datasheet's"}}
         out = {
             "metric": "selfplay_games_per_s",
             "value": games / elapsed,
@@ -419,8 +437,7 @@ def main():
                          "traffic_source": traffic_src,
                          "flop_per_leaf": FLOP_PER_LEAF[dom], "leaves_per_launch": leaves_per_launch,
                          "avg_launch_ms": avg_ms, "whole_net_tflops": net_tflops,
-                         "mfma_per_product": mfma_per_product,
-                         "issued_frac": achieved * mfma_per_product / PEAK_TFLOPS[args.precision],
+                         "mfma_per_product": mfma_per_product, **issued(achieved),
                          "concurrent_chains": chains,
                          "shader_clock_mhz": {k: round(v) for k, v in clocks.items()}, "peak_assumes_mhz": 2400,
                          "region_net_tflops": totals["net_leaves"] * sum(FLOP_PER_LEAF.values()) / (elapsed_rank0 * 1e12),
@@ -446,7 +463,7 @@ def main():
                 "kernel": KERNEL_NAME.get(dom, dom), "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
                 "frac": ach / PEAK_TFLOPS[args.precision], "traffic": tr, "traffic_source": src,
                 "leaves_per_launch": lpl, "avg_launch_ms": ms,
-                "issued_frac": ach * mfma_per_product / PEAK_TFLOPS[args.precision],
+                **issued(ach),
                 "flop_per_leaf": FLOP_PER_LEAF[dom], "mfma_per_product": mfma_per_product,
                 "shader_clock_mhz": {k: round(v) for k, v in clk1.items()}, "peak_assumes_mhz": 2400,
                 "kernel_ms": {k: round(v["avg_ms"], 4) for k, v in p1.items()},
