@@ -53,6 +53,37 @@ __global__ __launch_bounds__(256) void spin_random(int iters, float *out, unsign
     if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
 }
 
+// Does it matter for the power how the operands change from one instruction to the next?  ORDER 0: both operands change
+// every time (a0 b0, a1 b1, a2 b2, a3 b3).  ORDER 1: the 4 x 4 products in row order (a0 b0, a0 b1, a0 b2, a0 b3, a1 b0, ...:
+// B changes every time, A every fourth).  ORDER 2: the same products in snake order (a0 b0, a0 b1, a0 b2, a0 b3, a1 b3,
+// a1 b2, ...: exactly one operand changes per step).  16 accumulators, pseudo-random operands.
+template <int ORDER>
+__global__ __launch_bounds__(256) void spin_order(int iters, float *out, unsigned long long *clk) {
+    half8 a[4], b[4];
+    unsigned s = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 8; ++i) {
+            s = s * 1664525u + 1013904223u; a[j][i] = (_Float16)((float)(int)(s >> 8) / 8388608.0f - 1.0f);
+            s = s * 1664525u + 1013904223u; b[j][i] = (_Float16)((float)(int)(s >> 8) / 8388608.0f - 1.0f);
+        }
+    float4v c[16];
+    for (int j = 0; j < 16; ++j) c[j] = float4v{0, 0, 0, 0};
+    unsigned long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = ORDER == 0 ? k & 3 : k >> 2;
+            const int j = ORDER == 0 ? k & 3 : ORDER == 1 ? k & 3 : ((k >> 2) & 1 ? 3 - (k & 3) : k & 3);
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c[k]) : "v"(a[i]), "v"(b[j]));
+        }
+    }
+    unsigned long long t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    float r = 0;
+    for (int j = 0; j < 16; ++j) r += c[j][0] + c[j][1] + c[j][2] + c[j][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
+}
+
 // same FLOPs per iteration with the 16x16x32 instruction (8 accumulators of 4 registers; inline assembly, because the
 // compiler shuttles the builtin's accumulators through accumulation registers inside the loop)
 __global__ __launch_bounds__(256) void spin16(int iters, float *out, unsigned long long *clk) {
@@ -117,6 +148,21 @@ int main(int argc, char **argv) {
         double flop = (double)blocks * 4 * iters * 4 * 32768.0;
         printf("32x32x16, changing pseudo-random operands, rep %d: %.3f ms  %.1f TFLOP/s -> %.0f MHz\n", rep, ms, flop / (ms * 1e-3) / 1e12, (double)h[0] / (double)h[1] * 100.0);
     }
+    auto order_run = [&](auto kernel, const char *what) {
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0);
+            kernel<<<blocks, 256>>>(iters / 2, out, clk);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            unsigned long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+            double flop = (double)blocks * 4 * (iters / 2) * 16 * 16384.0;
+            printf("16x16x32, pseudo-random operands, %s, rep %d: %.3f ms  %.1f TFLOP/s\n", what, rep, ms, flop / (ms * 1e-3) / 1e12);
+        }
+    };
+    order_run(spin_order<0>, "both operands change every instruction");
+    order_run(spin_order<1>, "4 x 4 products in row order");
+    order_run(spin_order<2>, "4 x 4 products in snake order");
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
         spin<<<blocks, 256>>>(iters, out, clk);
