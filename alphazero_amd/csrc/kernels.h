@@ -27,7 +27,16 @@ void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, in
                       const RoundDev *turnover = nullptr, const GameSpan *span = nullptr);
 hipError_t prepare_tree_fused(size_t lds_bytes);
 hipError_t prepare_tree_step();
-void launch_tree_fused(hipStream_t st, const EngineDev &e, const SearchDev &p, size_t lds_bytes);
+// How the fused tree kernel uses its dynamic LDS for a search of `sims` simulations within `budget` bytes: the first
+// `nodes` nodes of the pool (all 1 + 7*sims of them unless `split`), the log table too if `logt`.
+struct FusedLds {
+    size_t bytes;
+    int nodes;
+    int logt;
+    bool split;
+};
+FusedLds fused_lds_plan(int sims, bool az, size_t budget);
+void launch_tree_fused(hipStream_t st, const EngineDev &e, const SearchDev &p, const FusedLds &f);
 void launch_readout(hipStream_t st, const EngineDev &e, const SearchDev &p, int32_t *visits_out,
                     int8_t *action_out, double *root_value_out, const RoundDev *round);
 void launch_trajectory_samples(hipStream_t st, int n, const nnb_trajectory *rec, const int32_t *ply_offsets, float *planes,

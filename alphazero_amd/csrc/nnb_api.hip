@@ -42,6 +42,15 @@ int fail(int code, const char *fmt, ...) {
 constexpr size_t kAlign = 256;
 constexpr int kMaxSims = 9000;           // first_child is 16 bit: 1 + 7*sims <= 65535
 constexpr size_t kFusedLdsLimit = 160 * 1024;   // LDS of one CU
+// The fused tree kernel's share of it when a search's whole pool would take more: sixteen games per CU (four waves per
+// SIMD, 4096 games resident at once on 256 CUs), the pool's first nodes in LDS and the rest in memory.  The kernel
+// is a chain of dependent loads per game, so its throughput follows the games in flight: 800 simulations under PUCT
+// with rollouts, 4096 games: 32 M sims/s with the whole pool in LDS (112 KB, one game per CU), 55 / 76 / 95 / 120 /
+// 145 / 187 M with a share of 78 / 52 / 39 / 26 / 13 / 10 KB, and no more below that (tools/tree_occupancy.py).
+#ifndef NNB_FUSED_LDS_KB
+#define NNB_FUSED_LDS_KB 10
+#endif
+constexpr size_t kFusedLdsShare = (size_t)NNB_FUSED_LDS_KB * 1024;
 constexpr int kHalvesMinSlots = 1024;    // below this a round is not split over two streams
 constexpr int kStepGamesHost = 16;       // games per block of the tree step kernel (halves are cut on a block boundary)
 constexpr int kProfClasses = 7;
@@ -531,22 +540,17 @@ int run_move(nnb_engine *e, hipStream_t st, const nnb_search_params &p, int32_t 
         make_noise = 1;
     }
     launch_tree_init(st, d, sd, make_noise, selfplay);
-    // the fused kernel keeps the node pool of this search in LDS; a search too long for that runs the
-    // lock-step path instead (same results), except random rollouts, which only the fused kernel draws
-    const size_t pool_nodes = 1 + 7 * (size_t)p.sims;
-    const size_t lds = pool_nodes * sizeof(Node) + (az ? pool_nodes * sizeof(float) : (size_t)(p.sims + 2) * sizeof(double));
-    const bool fits_lds = lds <= kFusedLdsLimit;
-    if (p.evaluator == NNB_EVAL_NET || (p.flags & NNB_FLAG_LOCKSTEP) || (!fits_lds && p.evaluator != NNB_EVAL_ROLLOUT)) {
+    // the fused kernel keeps the node pool of this search in LDS: all of it, or, when that is more than a game's
+    // share of the CU, its first nodes (the rest in the game's pool in memory: same results)
+    if (p.evaluator == NNB_EVAL_NET || (p.flags & NNB_FLAG_LOCKSTEP)) {
         const StepPlan plan = make_step_plan(e, p, sd);
         if (plan.nbatch == 2 && p.evaluator == NNB_EVAL_NET) ensure_side_stream(e, st);
         for (int s = 0; s <= p.sims; ++s) lockstep_step(e, st, p, sd, plan, s & 1, s < p.sims);
         *steps += p.sims;
     } else {
-        if (!fits_lds)
-            return fail(NNB_ERR_ARG, "sims = %d needs %zu bytes of LDS for the fused tree kernel (limit %zu)",
-                        p.sims, lds, kFusedLdsLimit);
-        if (int rc = ensure_tree_fused_lds(lds)) return rc;
-        { ProfScope ps(e, 0, st); launch_tree_fused(st, d, sd, lds); }
+        const FusedLds plan = fused_lds_plan(p.sims, az, kFusedLdsShare);
+        if (int rc = ensure_tree_fused_lds(plan.bytes)) return rc;
+        { ProfScope ps(e, 0, st); launch_tree_fused(st, d, sd, plan); }
         *steps += 1;
     }
     { ProfScope ps(e, 6, st); launch_readout(st, d, sd, visits_out, action_out, root_value_out, round); }
@@ -1220,17 +1224,17 @@ int nnb_search_static(void *stream, const nnb_search_params *p, int32_t n, const
         if (!(sd.dirichlet_alpha > 0.0)) return fail(NNB_ERR_ARG, "dirichlet_eps > 0 needs dirichlet_alpha > 0 or root_noise");
         make_noise = 1;
     }
-    const size_t pool_nodes = 1 + 7 * (size_t)p->sims;
-    const size_t lds = pool_nodes * sizeof(Node) + (az ? pool_nodes * sizeof(float) : (size_t)(p->sims + 2) * sizeof(double));
-    if (lds > kFusedLdsLimit) return fail(NNB_ERR_ARG, "sims = %d needs %zu bytes of LDS (limit %zu)", p->sims, lds, kFusedLdsLimit);
-    rc = ensure_tree_fused_lds(lds);
+    // no pools in memory behind this entry point: the whole pool in LDS
+    const FusedLds plan = fused_lds_plan(p->sims, az, kFusedLdsLimit);
+    if (plan.split) return fail(NNB_ERR_ARG, "sims = %d needs more than the %zu bytes of LDS of a CU", p->sims, kFusedLdsLimit);
+    rc = ensure_tree_fused_lds(plan.bytes);
     if (rc) return rc;
     EngineDev d = s->dev;                   // every pointer in it derives from the address hipGetSymbolAddress returned
     d.n_games = n;
     launch_search_init(st, d, reinterpret_cast<const u64 *>(root_colour_boards), root_players, side_players,
                        p->rng_game_base, root_noise);
     launch_tree_init(st, d, sd, make_noise, 0);
-    launch_tree_fused(st, d, sd, lds);
+    launch_tree_fused(st, d, sd, plan);
     launch_readout(st, d, sd, visits_out, action_out, root_value_out, nullptr);
     HIP_TRY(hipGetLastError());
     return NNB_OK;

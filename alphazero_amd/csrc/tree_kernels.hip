@@ -8,6 +8,7 @@
 // like the CPython expression it replaces (nnbattle/agents/alphazero/mcts.py:29).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 #include "c4_bits.h"
 #include "engine_layout.h"
 #include "kernels.h"
@@ -97,9 +98,20 @@ __global__ void ucb_scores_kernel(int n, const double *__restrict__ value, const
 }
 
 // ---------------------------------------------------------------------------
-// Wave-level search primitives (templated on nothing: Node* may point to global
-// memory or to LDS; after inlining the compiler resolves the address space).
+// Wave-level search primitives.  A pool is anything indexed by node number: a Node* (global memory or LDS; after
+// inlining the compiler resolves the address space) or a SplitArray, whose first nodes live in LDS and the rest in
+// memory.
 // ---------------------------------------------------------------------------
+// Elements 0 .. cap-1 in LDS, the others in memory at their own index: the top of a search tree is created first and
+// visited most, so a tree too large for its share of the LDS keeps its hot part there.
+template <typename T>
+struct SplitArray {
+    T *lds;
+    T *mem;
+    int cap;
+    __device__ __forceinline__ T &operator[](int i) const { return *(i < cap ? lds + i : mem + i); }
+};
+
 struct Descent {
     u64 c1, c2;     // colour boards at the leaf
     int node;       // leaf node index
@@ -112,7 +124,8 @@ struct Descent {
 // (connect_four_game.py:50) and flips it back at agent_code.py:176, so every stone
 // placed during descent has the root mover's colour.  `mypath` is this lane's entry of
 // the path (lane i holds the i-th node).
-__device__ __forceinline__ Descent descend_compat(const Node *pool, const double *logt, double c_puct,
+template <typename Pool>
+__device__ __forceinline__ Descent descend_compat(const Pool &pool, const double *logt, double c_puct,
                                                   int player, u64 c1, u64 c2, int lane, int &mypath) {
     Descent r;
     Node root = pool[0];
@@ -153,7 +166,8 @@ __device__ __forceinline__ Descent descend_compat(const Node *pool, const double
 
 // MCTSNode.expand (mcts.py:35-38): one child per legal column, ascending; the
 // reference discards the priors here.  Returns the number of children created.
-__device__ __forceinline__ int expand_compat(Node *pool, int node, int n_nodes, unsigned legal, int lane) {
+template <typename Pool>
+__device__ __forceinline__ int expand_compat(const Pool &pool, int node, int n_nodes, unsigned legal, int lane) {
     int nlegal = __popc(legal);
     if (lane < nlegal) {
         unsigned m = legal;
@@ -172,11 +186,12 @@ __device__ __forceinline__ int expand_compat(Node *pool, int node, int n_nodes, 
 
 // MCTSNode.backpropagate (mcts.py:40-44): +1 visit and the same un-negated value on
 // every node of the path; one node per lane, so no atomics.
-__device__ __forceinline__ void backup_path(Node *pool, int mypath, int len, double v, int lane) {
+template <typename Pool>
+__device__ __forceinline__ void backup_path(const Pool &pool, int mypath, int len, double v, int lane) {
     if (lane < len) {
-        Node *n = pool + mypath;
-        n->visits += 1;
-        n->value += v;
+        Node &n = pool[mypath];
+        n.visits += 1;
+        n.value += v;
     }
 }
 
@@ -320,7 +335,8 @@ struct DescentAz {
     bool terminal;
 };
 
-__device__ __forceinline__ DescentAz descend_az(const Node *pool, const float *prior, double c_puct, int player,
+template <typename Pool, typename Priors>
+__device__ __forceinline__ DescentAz descend_az(const Pool &pool, const Priors &prior, double c_puct, int player,
                                                 u64 c1, u64 c2, int lane, int &mypath) {
     DescentAz r;
     Node root = pool[0];
@@ -364,7 +380,8 @@ __device__ __forceinline__ DescentAz descend_az(const Node *pool, const float *p
 }
 
 // Children with priors; `pr` is the prior of column `lane` (lanes 0..6).
-__device__ __forceinline__ int expand_az(Node *pool, float *prior, int node, int n_nodes, unsigned legal, float pr,
+template <typename Pool, typename Priors>
+__device__ __forceinline__ int expand_az(const Pool &pool, const Priors &prior, int node, int n_nodes, unsigned legal, float pr,
                                          int lane) {
     const int nlegal = __popc(legal);
     unsigned m = legal;
@@ -385,11 +402,12 @@ __device__ __forceinline__ int expand_az(Node *pool, float *prior, int node, int
 }
 
 // v = value for the side to move at the leaf; the leaf gets -v, its parent +v, ...
-__device__ __forceinline__ void backup_az(Node *pool, int mypath, int len, double v, int lane) {
+template <typename Pool>
+__device__ __forceinline__ void backup_az(const Pool &pool, int mypath, int len, double v, int lane) {
     if (lane < len) {
-        Node *n = pool + mypath;
-        n->visits += 1;
-        n->value += ((len - 1 - lane) & 1) ? v : -v;
+        Node &n = pool[mypath];
+        n.visits += 1;
+        n.value += ((len - 1 - lane) & 1) ? v : -v;
     }
 }
 
@@ -693,22 +711,40 @@ __global__ __launch_bounds__(kStepGames * 64) void tree_step_kernel(EngineDev e,
 // ---------------------------------------------------------------------------
 // K2, fused form (fixed evaluators: CONST / HASH / ROLLOUT): the whole search of one move
 // in one launch, the node pool resident in LDS.  One 64-thread block (one wavefront) per
-// game.  Dynamic LDS: (1 + 7*sims)*16 bytes of nodes, then (COMPAT) the log table of sims+2
-// doubles or (AZ) one float prior per node.
+// game.  Dynamic LDS: lds_nodes * 16 bytes of nodes, then (COMPAT) the log table of sims+2
+// doubles, unless lds_logt is 0 and it is read from memory, or (AZ) one float prior per node.
+// SPLIT = false: lds_nodes = 1 + 7*sims, the whole pool.  SPLIT = true: the search may create more
+// nodes than its share of the LDS holds (a CU has 160 KB, and one wave per CU leaves three of its
+// four SIMDs idle: 800 simulations need 112 KB); nodes lds_nodes and up then live in the game's
+// pool in memory (SplitArray), so that several games share a CU whatever the simulation count.
 // ---------------------------------------------------------------------------
-template <bool AZ>
-__global__ __launch_bounds__(64) void tree_fused_kernel(EngineDev e, SearchDev p) {
+template <bool AZ, bool SPLIT>
+__global__ __launch_bounds__(64) void tree_fused_kernel(EngineDev e, SearchDev p, int lds_nodes, int lds_logt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const int g = blockIdx.x;
     if (g >= e.n_games) return;
     if (!e.active[g]) return;
-    const size_t pool_nodes = 1 + 7 * (size_t)p.sims;          // nodes this search can create
-    Node *pool = reinterpret_cast<Node *>(smem);
-    double *logt = reinterpret_cast<double *>(smem + pool_nodes * sizeof(Node));
-    float *prior = reinterpret_cast<float *>(smem + pool_nodes * sizeof(Node));
-    if (!AZ)
-        for (int i = lane; i < p.sims + 2; i += 64) logt[i] = e.log_table[i];
+    Node *lpool = reinterpret_cast<Node *>(smem);
+    double *llogt = reinterpret_cast<double *>(smem + (size_t)lds_nodes * sizeof(Node));
+    float *lprior = reinterpret_cast<float *>(smem + (size_t)lds_nodes * sizeof(Node));
+    const double *logt = e.log_table;
+    if (!AZ && lds_logt) {
+        for (int i = lane; i < p.sims + 2; i += 64) llogt[i] = e.log_table[i];
+        logt = llogt;
+    }
+    Node *gpool = e.nodes + (size_t)g * e.pool_cap;
+    using Pool = std::conditional_t<SPLIT, SplitArray<Node>, Node *>;
+    using Priors = std::conditional_t<SPLIT, SplitArray<float>, float *>;
+    Pool pool;
+    Priors prior;
+    if constexpr (SPLIT) {
+        pool = {lpool, gpool, lds_nodes};
+        prior = {lprior, e.prior + (size_t)g * e.pool_cap, lds_nodes};
+    } else {
+        pool = lpool;
+        prior = lprior;
+    }
     if (lane == 0) {
         Node r;
         r.value = 0.0; r.visits = AZ ? 0 : 1; r.first_child = 0; r.nchild = 0; r.action = 0xFF;
@@ -766,8 +802,7 @@ __global__ __launch_bounds__(64) void tree_fused_kernel(EngineDev e, SearchDev p
         __syncthreads();
     }
     // hand the root and its children to the readout kernel through the global pool
-    Node *gpool = e.nodes + (size_t)g * e.pool_cap;
-    if (lane < 8 && lane < n_nodes) gpool[lane] = pool[lane];
+    if (lane < 8 && lane < n_nodes) gpool[lane] = lpool[lane];
     if (lane == 0) {
         e.sims_done[g] = p.sims;
         e.n_nodes[g] = n_nodes;
@@ -1172,11 +1207,15 @@ void launch_tree_step(hipStream_t st, const EngineDev &e, const SearchDev &p, in
 }
 
 hipError_t prepare_tree_fused(size_t lds_bytes) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(tree_fused_kernel<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (err != hipSuccess) return err;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(tree_fused_kernel<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    const void *k[4] = {reinterpret_cast<const void *>(tree_fused_kernel<false, false>),
+                        reinterpret_cast<const void *>(tree_fused_kernel<true, false>),
+                        reinterpret_cast<const void *>(tree_fused_kernel<false, true>),
+                        reinterpret_cast<const void *>(tree_fused_kernel<true, true>)};
+    for (const void *f : k) {
+        hipError_t err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (err != hipSuccess) return err;
+    }
+    return hipSuccess;
 }
 
 // The PUCT step kernel of a two-network arena stages 2 x 8 head rows = 64 KB of dynamic LDS.
@@ -1192,9 +1231,35 @@ hipError_t prepare_tree_step() {
     return hipSuccess;
 }
 
-void launch_tree_fused(hipStream_t st, const EngineDev &e, const SearchDev &p, size_t lds_bytes) {
-    if (p.mode == NNB_MODE_AZ) tree_fused_kernel<true><<<e.n_games, 64, lds_bytes, st>>>(e, p);
-    else tree_fused_kernel<false><<<e.n_games, 64, lds_bytes, st>>>(e, p);
+FusedLds fused_lds_plan(int sims, bool az, size_t budget) {
+    FusedLds f;
+    const size_t pool_nodes = 1 + 7 * (size_t)sims;
+    const size_t logt_bytes = az ? 0 : (size_t)(sims + 2) * sizeof(double);
+    const size_t per_node = sizeof(Node) + (az ? sizeof(float) : 0);
+    f.nodes = (int)pool_nodes;
+    f.logt = !az;
+    f.bytes = pool_nodes * per_node + logt_bytes;
+    if (f.bytes > budget) {
+        // a log table that would take more than a quarter of the share is read from memory instead
+        f.logt = !az && logt_bytes * 4 <= budget;
+        const size_t left = budget - (f.logt ? logt_bytes : 0);
+        f.nodes = (int)(left / per_node);
+        if (f.nodes > (int)pool_nodes) f.nodes = (int)pool_nodes;
+        f.bytes = (size_t)f.nodes * per_node + (f.logt ? logt_bytes : 0);
+    }
+    f.split = f.nodes < (int)pool_nodes;
+    return f;
+}
+
+void launch_tree_fused(hipStream_t st, const EngineDev &e, const SearchDev &p, const FusedLds &f) {
+    const bool az = p.mode == NNB_MODE_AZ;
+    if (f.split) {
+        if (az) tree_fused_kernel<true, true><<<e.n_games, 64, f.bytes, st>>>(e, p, f.nodes, f.logt);
+        else tree_fused_kernel<false, true><<<e.n_games, 64, f.bytes, st>>>(e, p, f.nodes, f.logt);
+    } else {
+        if (az) tree_fused_kernel<true, false><<<e.n_games, 64, f.bytes, st>>>(e, p, f.nodes, f.logt);
+        else tree_fused_kernel<false, false><<<e.n_games, 64, f.bytes, st>>>(e, p, f.nodes, f.logt);
+    }
 }
 
 void launch_dirichlet_noise(hipStream_t st, int n, u64 seed, const int32_t *game_ids, const int32_t *move_index,

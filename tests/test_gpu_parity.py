@@ -444,11 +444,13 @@ def test_net_search_sided_positions(seed0_engine, oracle, sided_golden):
         assert action.tolist() == [x["action"] for x in cases]
 
 
+@pytest.mark.parametrize("lockstep", [False, True])
 @pytest.mark.parametrize("mode", ["compat", "az"])
-def test_search_at_the_largest_simulation_count(oracle, mode):
+def test_search_at_the_largest_simulation_count(oracle, mode, lockstep):
     """9000 simulations per move is the most a 16-bit child index allows (1 + 7 * 9000 nodes per pool).  The pool
-    no longer fits LDS, so the fixed evaluator runs through the lock-step path; visits, move and root value must
-    still be the CPU search's, bit for bit, deep into a pool of 63 001 nodes."""
+    is far larger than the LDS: the fused kernel keeps its first nodes there and the rest in memory (and its log
+    table in memory too), the lock-step path all of it in memory; visits, move and root value must still be the
+    CPU search's, bit for bit, deep into a pool of 63 001 nodes."""
     from alphazero_amd.engine import Engine
     co, rp = oracle
     sims = 9000
@@ -459,7 +461,8 @@ def test_search_at_the_largest_simulation_count(oracle, mode):
     try:
         with pytest.raises(Exception, match="max_sims"):
             Engine(max_games=1, max_sims=sims + 1)
-        visits, action, rootv, stats = eng.search(boards, players, eng.params(sims, 1.4, evaluator="hash_f32", mode=mode))
+        visits, action, rootv, stats = eng.search(boards, players,
+                                                  eng.params(sims, 1.4, evaluator="hash_f32", mode=mode, lockstep=lockstep))
     finally:
         eng.close()
     for i, (b1, b2, player) in enumerate(pos):

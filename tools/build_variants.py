@@ -26,10 +26,20 @@ VARIANTS = {
     "look32": ["-DNNB_LOOK_ROUNDS=32"],
     "look128": ["-DNNB_LOOK_ROUNDS=128"],
     "look256": ["-DNNB_LOOK_ROUNDS=256"],
+    "lds3": ["-DNNB_FUSED_LDS_KB=3"],
+    "lds5": ["-DNNB_FUSED_LDS_KB=5"],
+    "lds7": ["-DNNB_FUSED_LDS_KB=7"],
+    "lds10": ["-DNNB_FUSED_LDS_KB=10"],
+    "lds13": ["-DNNB_FUSED_LDS_KB=13"],
+    "lds19": ["-DNNB_FUSED_LDS_KB=19"],
+    "lds26": ["-DNNB_FUSED_LDS_KB=26"],
+    "lds31": ["-DNNB_FUSED_LDS_KB=31"],
+    "lds52": ["-DNNB_FUSED_LDS_KB=52"],
+    "lds78": ["-DNNB_FUSED_LDS_KB=78"],
 }
 AFFECTED = {"NNB_TERMINAL_SIMS_PER_STEP": ["tree_kernels.hip"], "NNB_LOOK_ROUNDS": ["nnb_api.hip"],
             "NNB_STREAM_PROBE": ["nnb_api.hip"], "NNB_FC_SMALL_ROWS": ["net_kernels_split.hip"],
-            "NNB_FC_SMALL_DEPTH": ["net_kernels_split.hip"]}
+            "NNB_FC_SMALL_DEPTH": ["net_kernels_split.hip"], "NNB_FUSED_LDS_KB": ["nnb_api.hip"]}
 
 
 def main():
