@@ -33,11 +33,12 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   cpu_baseline : the CPU restatement of the reference path (oracle/ref_port.py: numpy board,
                  one game at a time, batch-1 torch-CPU forward) timed on this box's host cores
                  on a bounded sample, at 200 and at 100 simulations per move (rank 0, N=1 only);
-  single_round_identical_games, single_round_distinct_games, with_eval_cache, az_mode, f16_inputs (N=1 only,
+  single_round_identical_games, single_round_distinct_games, with_eval_cache, az_mode, f16_inputs, tree_only_800_sims (N=1 only,
                  each timed on its own, none part of `value`): the 4096 games from the empty board the reference
                  itself would play (one game, 4096 times) as one plain round; 16384 of the timed region's games as
                  one plain round; the stream with the per-game evaluation cache; a stream under the PUCT rule with
-                 Dirichlet root noise; and the headline stream with half-precision network inputs.
+                 Dirichlet root noise; the headline stream with half-precision network inputs; and the tree kernels
+                 without the network (800 simulations per move, random play-outs: BASELINE.json's pure-tree configuration).
 """
 from __future__ import annotations
 
@@ -337,6 +338,32 @@ def main():
                 "one step of the same stream with the inputs of every product rounded to half precision (f32 accumulate): "
                 "narrower than the reference's float32, so not comparable with `value`")
             e16.close()
+
+    if extras:
+        # the tree kernels without the network (the pure-tree configuration of BASELINE.json): one plain round of G games
+        # at 800 simulations per move under PUCT, uniform priors, a random play-out on bitboards as the leaf's value
+        et = Engine(max_games=G, max_sims=800, device=device, precision=args.precision)
+        pt = et.params(800, C_PUCT, evaluator="rollout", mode="az", seed=7)
+        et.selfplay_round(min(G, 256), pt)
+        kept = {}
+
+        def tree_round():
+            kept["st"] = et.selfplay_round(G, pt)[1]
+            return kept["st"]
+        line = timed(
+            tree_round,
+            f"one plain round of {G} games at 800 simulations per move under PUCT with uniform priors and a uniformly "
+            "random play-out on bitboards as every leaf's value (no network): the whole move of a game in one launch of "
+            "the fused tree kernel, sixteen games per CU; hbm_frac = algorithmic bytes (112 x mean depth + 212 per "
+            "simulation) over the round's wall time against 8 TB/s: small by design, the kernel is a chain of "
+            "dependent loads per game")
+        depth = kept["st"]["depth_sum"] / max(kept["st"]["sims"], 1)
+        line["mean_selection_depth"] = depth
+        line["algorithmic_bytes_per_sim"] = 112.0 * depth + 212.0
+        line["achieved_gbs"] = line["sims_per_s"] * line["algorithmic_bytes_per_sim"] / 1e9
+        line["hbm_frac"] = line["achieved_gbs"] / PEAK_HBM_GBS
+        extra["tree_only_800_sims"] = line
+        et.close()
 
     # all-gather cost alone (reported, also part of the timed region above)
     gather_ms = None
