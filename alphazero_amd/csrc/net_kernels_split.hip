@@ -802,7 +802,8 @@ constexpr int FCS_ROW_BYTES = 90 * 512;                      // one activation r
 // LDS slab buffer: 128 rows of 16 pieces of 16 bytes (8 hi, 8 lo) + one pad piece, so that the 16 rows one
 // ds_read_b128 services together fall on 16 different bank groups and every fragment address is the lane's
 // base plus a compile-time offset.
-constexpr int FCS_BR = 6;                                    // weight fragments in flight, in k-steps (+1)
+[[maybe_unused]] constexpr int FCS_BR = 6;                   // weight fragments in flight, in k-steps of 16 (+1): fc_split_kernel
+[[maybe_unused]] constexpr int FC16_BR = 3;                  // the same in k-steps of 32: fc16_kernel
 constexpr int FCS_LROW = 17 * 16;                            // bytes per row in LDS
 constexpr int FCS_LBUF = 128 * FCS_LROW;                     // bytes per buffer
 
@@ -1242,6 +1243,397 @@ __global__ __launch_bounds__(64) void fc_split_small_kernel(const u32x4 *__restr
     if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[2] = __builtin_readcyclecounter(); clk[3] = wall_clock64(); }
 }
 
+// ---------------------------------------------------------------------------
+// The same linear layer on v_mfma_f32_16x16x32_f16 (fc16_*).  Under the socket's power cap this instruction shape
+// delivers more than 32x32x16 on changing data (half the accumulator traffic per FLOP: tools/mfma_peak.hip), and the
+// layer's time follows the clock the cap allows.  Block tile, K split, LDS slabs, weight layout, XCD mapping, the
+// meeting of the two K halves and the heads' sums are those of fc_split_kernel; what changes is the shape of a wave's
+// tiles: its 64 columns are FOUR 16-column tiles, the block's rows 16-row tiles, a k-step is 32 k.  Lane l supplies row
+// l % 16 (A) / column l % 16 (B) for k = 8 * (l / 16) .. + 7 - LDS piece 4 * ks + l / 16 of the slab (hi; + 8: lo),
+// weight piece (4 * kstep + l / 16) * 1024 + n - and holds D[4 * (l / 16) + r][l % 16], r = 0..3.
+// Per accumulator and k-step: hi*lo, lo*hi, hi*hi over 32 k-values, k-steps ascending - the order both forms
+// (fc16_kernel, fc16_small_kernel) keep, so that their results agree bit for bit.
+// ---------------------------------------------------------------------------
+
+// Sum over the 32 columns of a 32-column group of x * head weight, for the four rows a lane holds: the group is two
+// 16-column tiles (columns c and c ^ 16 sit in the same lane: the tree's first level is an addition in place), then
+// lanes 8, 4, 2, 1 apart; each of the first two exchanges halves the rows a lane carries.  Same tree as
+// tile_column_sum.  Returns the sum of row 2 * bit3(m) + bit2(m).
+__device__ __forceinline__ float fc16_group_sum(const f32x4 &xa, const f32x4 &xb, float hwa, float hwb, int m) {
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] = __fadd_rn(__fmul_rn(xa[r], hwa), __fmul_rn(xb[r], hwb));
+    const bool b3 = m & 8, b2 = m & 4;
+    float v2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) v2[i] = (b3 ? p[2 + i] : p[i]) + lane_xor<8>(b3 ? p[i] : p[2 + i]);
+    float v1 = (b2 ? v2[1] : v2[0]) + lane_xor<4>(b2 ? v2[0] : v2[1]);
+    v1 = v1 + lane_xor<2>(v1);
+    return v1 + lane_xor<1>(v1);
+}
+
+// fc_split_finish for 16x16 tiles: acc[t][u] covers rows row0 + 16 t .. + 15 and columns col0 + 16 u .. + 15 (col0 a
+// multiple of 32, CT even).  hand_base: float offset of the pair's hand-off area (NW * RT * CT * 256 floats).
+template <int RT, int CT, int NW>
+__device__ __forceinline__ void fc16_finish(f32x4 (&acc)[RT][CT], const FcFinish &fin, const float *__restrict__ a_inv_scale,
+                                            float inv_sw, unsigned ticket, int pair, size_t hand_base, int row0,
+                                            int count, int max_rows, int col0, int wave, int lane) {
+    static_assert(CT % 2 == 0, "two 16-column tiles form a 32-column group of the heads' sums");
+    const int m = lane & 15, g = lane >> 4;
+    static_for<RT>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = min(row0 + 16 * t + 4 * g + r, max_rows - 1);
+            const float k = a_inv_scale[row] * inv_sw;
+#pragma unroll
+            for (int u = 0; u < CT; ++u) acc[t][u][r] *= k;
+        }
+    });
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(fin.handoff + hand_base, 0, NW * RT * CT * 256 * 4, 0x00027000);
+    const int hoff = (wave * RT * CT * 64 + lane) * 16;                // + (t * CT + u) * 1024 bytes
+    if ((ticket & 1u) == 0u) {                                          // first of the pair: hand the tile over and leave
+        static_for<RT>([&](auto T) __attribute__((always_inline)) {
+            constexpr int t = decltype(T)::value;
+#pragma unroll
+            for (int u = 0; u < CT; ++u) {
+                u32x4 v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = __float_as_uint(acc[t][u][c]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rh, hoff + (t * CT + u) * 1024, 0, 16);    // 16 = sc1: write-through
+            }
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(fin.flag + pair, ticket + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (threadIdx.x == 0) {
+        bool seen = false;
+        for (int spin = 0; spin < (1 << 20); ++spin) {
+            if (__hip_atomic_load(fin.flag + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ticket) { seen = true; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (!seen) atomicAdd(fin.err, 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    float bias[CT];
+#pragma unroll
+    for (int u = 0; u < CT; ++u) bias[u] = fin.fc_bias[col0 + 16 * u + m];
+    static_for<RT>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+#pragma unroll
+        for (int u = 0; u < CT; ++u) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rh, hoff + (t * CT + u) * 1024, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[t][u][c] = fmaxf((acc[t][u][c] + __uint_as_float(v[c])) + bias[u], 0.f);
+        }
+    });
+    if (fin.hidden) {
+        static_for<RT>([&](auto T) __attribute__((always_inline)) {
+            constexpr int t = decltype(T)::value;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 16 * t + 4 * g + r;
+#pragma unroll
+                for (int u = 0; u < CT; ++u)
+                    if (row < count) fin.hidden[(size_t)row * FCS_N + col0 + 16 * u + m] = acc[t][u][r];
+            }
+        });
+    }
+    const int rkeep = ((m >> 3) & 1) * 2 + ((m >> 2) & 1);               // the row this lane ends up with
+    for (int o = fin.heads_all ? 0 : 7; o < 8; ++o) {
+        float hw[CT];
+#pragma unroll
+        for (int u = 0; u < CT; ++u) hw[u] = fin.heads_w[o * FCS_N + col0 + 16 * u + m];
+        static_for<RT>([&](auto T) __attribute__((always_inline)) {
+            constexpr int t = decltype(T)::value;
+#pragma unroll
+            for (int v = 0; v < CT / 2; ++v) {
+                const float sum = fc16_group_sum(acc[t][2 * v], acc[t][2 * v + 1], hw[2 * v], hw[2 * v + 1], m);
+                const int row = row0 + 16 * t + 4 * g + rkeep;
+                if (!(m & 3) && row < count) fin.q[(size_t)row * 256 + o * 32 + col0 / 32 + v] = sum;
+            }
+        });
+    }
+}
+
+// One matrix instruction with the accumulator tied to an accumulation register.  (Through the builtin the register
+// allocator moves the 32 four-register accumulators of fc16_tile around between instructions: 405 copies per 1152
+// instructions.)  The operands come from memory and LDS loads, whose waits the compiler places for the statement's
+// inputs; a dependent instruction on the same accumulator follows at a distance of CT instructions.
+#define NNB_FC16_MFMA(A, B, C) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(C) : "v"(A), "v"(B))
+
+template <int MTR, int BR>
+__device__ __forceinline__ void fc16_tile(const u32x4 *__restrict__ a, const float *__restrict__ a_inv_scale,
+                                          const u32x4 *__restrict__ wph, const u32x4 *__restrict__ wpl,
+                                          const SplitScales *__restrict__ sc, const FcFinish &fin, int count,
+                                          int max_rows, unsigned char *lds, int mbx) {
+    const int bid = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, m = lane & 15, g = lane >> 4;
+    // the mapping of blocks to (row block, column block, K half) of fc_split_tile
+    const int x = bid & 7, i = bid >> 3;
+    const int per = 8 * mbx;
+    const int grp = i / per, ii = i - grp * per;
+    const int q = 2 * mbx;
+    const int mb = grp * 8 * mbx + (x & 3) * q + ii % q;
+    const int nb = (x >> 2) * 2 + ((ii / q) & 1), ksp = ii / (2 * q);
+    const int row0 = mb * (32 * MTR);
+    if (row0 >= count) return;
+    NNB_SP_STAMP(0) NNB_SP_WALL(5)
+
+    constexpr int KHALF = FCS_K / FCS_SPLIT;                 // 5760
+    constexpr int NSLAB = KHALF / FCS_BK;                    // 90 slabs of 64 k = 2 k-steps of 32
+    constexpr int NKS = NSLAB * 2;
+    constexpr int RT = 2 * MTR, CT = 4;                      // 16-row tiles, 16-column tiles
+    constexpr int NCH = RT;                                  // staging chunks per thread and slab (16 rows each)
+    static_assert(NSLAB % 6 == 0 && 12 % BR == 0, "the slab loop is unrolled by 6 (3 LDS buffers x 2 register sets)");
+    const int slab0 = ksp * NSLAB;
+    const int prow = tid >> 4, pq = tid & 15;
+    const int rows_here = min(max_rows - row0, 32 * MTR);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char *>(reinterpret_cast<const unsigned char *>(a) + (size_t)row0 * FCS_ROW_BYTES), 0,
+        rows_here * FCS_ROW_BYTES, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(wph), 0, FCS_K * FCS_N * 2, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(wpl), 0, FCS_K * FCS_N * 2, 0x00027000);
+    unsigned aoff[NCH];
+    static_for<NCH>([&](auto C) __attribute__((always_inline)) {
+        constexpr int c = decltype(C)::value;
+        const int r = min(row0 + 16 * c + prow, max_rows - 1) - row0;
+        aoff[c] = (unsigned)r * FCS_ROW_BYTES + (pq & 7) * 16 + (pq >> 3) * 256;
+    });
+    unsigned char *sdst = lds + prow * FCS_LROW + pq * 16;                   // + c * 16 rows, + buffer
+    auto slab_bytes = [&](int s) __attribute__((always_inline)) { const int sg = slab0 + s; return (sg >> 1) * 512 + (sg & 1) * 128; };
+    auto load_a = [&](int s, unsigned c_off) __attribute__((always_inline)) {
+        return __builtin_amdgcn_raw_buffer_load_b128(ra, (int)c_off, slab_bytes(s), 0);
+    };
+    u32x4 stg[2][NCH];
+    // prologue: slabs 0 and 1 into LDS, slabs 2 and 3 in flight in the two register sets
+    static_for<NCH>([&](auto C) __attribute__((always_inline)) {
+        constexpr int c = decltype(C)::value;
+        stg[0][c] = load_a(0, aoff[c]); stg[1][c] = load_a(1, aoff[c]);
+    });
+    static_for<NCH>([&](auto C) __attribute__((always_inline)) {
+        constexpr int c = decltype(C)::value;
+        *reinterpret_cast<u32x4 *>(sdst + c * 16 * FCS_LROW) = stg[0][c];
+        *reinterpret_cast<u32x4 *>(sdst + FCS_LBUF + c * 16 * FCS_LROW) = stg[1][c];
+    });
+    static_for<NCH>([&](auto C) __attribute__((always_inline)) {
+        constexpr int c = decltype(C)::value;
+        stg[0][c] = load_a(2, aoff[c]); stg[1][c] = load_a(3, aoff[c]);
+    });
+    __syncthreads();
+
+    f32x4 acc[RT][CT];
+    static_for<RT>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+#pragma unroll
+        for (int u = 0; u < CT; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    });
+    // weight piece of (k-step of 32, column tile u): ((4 * kstep + g) * 1024 + n) * 16 bytes, n = 256 nb + 64 w + 16 u + m
+    constexpr int WKS = 4 * FCS_N * 16;                      // bytes per k-step
+    const int wbase = ((ksp * KHALF / 32) * 4 * FCS_N + nb * 256) * 16;
+    const int woff = (g * FCS_N + w * 64 + m) * 16;
+    auto load_w = [&](const __amdgpu_buffer_rsrc_t &r, int kstep, int u) __attribute__((always_inline)) {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, woff + u * 256, wbase + kstep * WKS, 0);
+    };
+    u32x4 bh[BR][CT], bl[BR][CT];
+    static_for<BR - 1>([&](auto Jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(Jc)::value;
+#pragma unroll
+        for (int u = 0; u < CT; ++u) { bh[j][u] = load_w(rwh, j, u); bl[j][u] = load_w(rwl, j, u); }
+    });
+    // fragment of (buffer, row tile t, k-step ks of the slab): row 16t + m, piece 4*ks + g (hi), 8 + 4*ks + g (lo)
+    const unsigned char *fbase = lds + m * FCS_LROW + g * 16;
+    auto frag = [&](int buf, int t, int ks, int lo) __attribute__((always_inline)) {
+        return *reinterpret_cast<const u32x4 *>(fbase + buf * FCS_LBUF + t * 16 * FCS_LROW + ks * 64 + lo * 128);
+    };
+    // fragments run AHEAD row tiles ahead of their use through a ring of AHEAD + 1 register sets
+    constexpr int AHEAD = RT > 3 ? 3 : RT - 1, NSETS = AHEAD + 1;
+    static_assert((RT * 12) % NSETS == 0, "the ring's period divides the unrolled body");
+    u32x4 fh[NSETS], fl[NSETS];
+    static_for<AHEAD>([&](auto T) __attribute__((always_inline)) {
+        constexpr int t = decltype(T)::value;
+        fh[t] = frag(0, t, 0, 0);
+        fl[t] = frag(0, t, 0, 1);
+    });
+
+    for (int s6 = 0; s6 < NSLAB; s6 += 6) {
+        static_for<6>([&](auto Uc) __attribute__((always_inline)) {
+            constexpr int U = decltype(Uc)::value;
+            const int s = s6 + U;
+            constexpr int buf = U % 3, set = U & 1;
+            static_for<2>([&](auto Kc) __attribute__((always_inline)) {
+                constexpr int ks = decltype(Kc)::value;
+                constexpr int J = U * 2 + ks;                    // k-step inside the 12-step body
+                constexpr int slot = J % BR, fill = (J + BR - 1) % BR;
+                int knext = s * 2 + ks + BR - 1;
+                knext = knext < NKS ? knext : NKS - 1;
+                constexpr int nbuf = ks < 1 ? buf : (U + 1) % 3; // where the next k-step's fragments live
+                constexpr int nks = (ks + 1) & 1;
+                static_for<RT>([&](auto T) __attribute__((always_inline)) {
+                    constexpr int t = decltype(T)::value;
+                    constexpr int cur = (J * RT + t) % NSETS, nxt = (J * RT + t + AHEAD) % NSETS;
+                    if constexpr (t + AHEAD < RT) {              // a later row tile's fragments of this k-step
+                        fh[nxt] = frag(buf, t + AHEAD, ks, 0);
+                        fl[nxt] = frag(buf, t + AHEAD, ks, 1);
+                    } else {                                     // the first row tiles of the next k-step (after the last: read, never used)
+                        fh[nxt] = frag(nbuf, t + AHEAD - RT, nks, 0);
+                        fl[nxt] = frag(nbuf, t + AHEAD - RT, nks, 1);
+                    }
+                    const u32x4 xh = fh[cur], xl = fl[cur];
+                    // per accumulator hi*lo, lo*hi, hi*hi; the four column tiles in between
+#pragma unroll
+                    for (int u = 0; u < CT; ++u) NNB_FC16_MFMA(xh, bl[slot][u], acc[t][u]);
+#pragma unroll
+                    for (int u = 0; u < CT; ++u) NNB_FC16_MFMA(xl, bh[slot][u], acc[t][u]);
+#pragma unroll
+                    for (int u = 0; u < CT; ++u) NNB_FC16_MFMA(xh, bh[slot][u], acc[t][u]);
+                    // memory instructions behind every row tile's 12 MFMAs: weights of k-step J + BR - 1 (the ring
+                    // slot's last reader was the previous k-step), column tiles t, t + RT, ...
+#pragma unroll
+                    for (int u = t; u < CT; u += RT) {
+                        bh[fill][u] = load_w(rwh, knext, u);
+                        bl[fill][u] = load_w(rwl, knext, u);
+                    }
+                    if constexpr (ks == 0) {                     // slab s+2: registers -> LDS (past the last slab this
+                        *reinterpret_cast<u32x4 *>(sdst + ((U + 2) % 3) * FCS_LBUF + t * 16 * FCS_LROW) = stg[set][t];   // rewrites a buffer nobody reads any more)
+                    } else {                                     // slab s+4: global -> registers
+                        stg[set][t] = load_a(s + 4 < NSLAB ? s + 4 : NSLAB - 1, aoff[t]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+            __syncthreads();
+        });
+    }
+    // the compiler does not see matrix instructions in the statements above: their last results are in place
+    // 4 passes after issue, well inside these wait states
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+    const int pair = mb * 4 + nb;
+    if (tid == 0)
+        *reinterpret_cast<unsigned *>(lds) = __hip_atomic_fetch_add(fin.ticket + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = *reinterpret_cast<const unsigned *>(lds);
+    fc16_finish<RT, CT, 4>(acc, fin, a_inv_scale, sc->inv_swf, ticket, pair,
+                           (size_t)row0 * FCS_N + (size_t)nb * (32 * MTR * 256), row0, count, max_rows,
+                           nb * 256 + w * 64, w, lane);
+    NNB_SP_STAMP(3) NNB_SP_WALL(6)
+}
+
+template <int BR>
+__global__ __launch_bounds__(256, 1) void fc16_kernel(const u32x4 *__restrict__ a,          // [rows][90][32 chunks]
+                                                      const float *__restrict__ a_inv_scale, // [rows]
+                                                      const u32x4 *__restrict__ wph, const u32x4 *__restrict__ wpl,
+                                                      const SplitScales *__restrict__ sc, FcFinish fin,
+                                                      const int32_t *__restrict__ count_ptr, int n_fixed,
+                                                      int max_rows, int shared_chip, unsigned long long *__restrict__ clk) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * FCS_LBUF];    // three slab buffers
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter(); clk[1] = wall_clock64(); }
+    const int count = batch_count_sp(count_ptr, n_fixed);
+    int mblocks = gridDim.x >> 3;                            // row blocks the grid provides (8 column/K blocks each)
+    int mbx = 4;
+    if (shared_chip && gridDim.x == 256 && count > 1024 && count <= 2048) {   // as fc_split_kernel
+        if (blockIdx.x >= 128) return;
+        mblocks = 16;
+        mbx = 2;
+    }
+    const int tiles = (count + 32 * mblocks - 1) / (32 * mblocks);
+    if (tiles <= 1) fc16_tile<1, BR>(a, a_inv_scale, wph, wpl, sc, fin, count, max_rows, lds, mbx);
+    else if (tiles == 2) fc16_tile<2, BR>(a, a_inv_scale, wph, wpl, sc, fin, count, max_rows, lds, mbx);
+    else if (tiles == 3) fc16_tile<3, BR>(a, a_inv_scale, wph, wpl, sc, fin, count, max_rows, lds, mbx);
+    else fc16_tile<4, BR>(a, a_inv_scale, wph, wpl, sc, fin, count, max_rows, lds, mbx);
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[2] = __builtin_readcyclecounter(); clk[3] = wall_clock64(); }
+}
+
+// Small batches on the same tiles (cf. fc_split_small_kernel): a block is ONE wave that owns 32 rows x 32 columns x
+// one half of K as 2 x 2 tiles of 16 x 16; fragments memory -> registers through a ring DEPTH k-steps (of 32) deep.
+template <int DEPTH>
+__global__ __launch_bounds__(64) void fc16_small_kernel(const u32x4 *__restrict__ a, const float *__restrict__ a_inv_scale,
+                                                        const u32x4 *__restrict__ wph, const u32x4 *__restrict__ wpl,
+                                                        const SplitScales *__restrict__ sc, FcFinish fin,
+                                                        const int32_t *__restrict__ count_ptr, int n_fixed, int max_rows,
+                                                        unsigned long long *__restrict__ clk) {
+    const int count = batch_count_sp(count_ptr, n_fixed);
+    const int bid = blockIdx.x, rt = bid >> 6, ct = (bid >> 1) & 31, ksp = bid & 1;
+    const int row0 = rt * 32;
+    if (row0 >= count) return;
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter(); clk[1] = wall_clock64(); }
+    const int lane = threadIdx.x, m = lane & 15, g = lane >> 4;
+    constexpr int KHALF = FCS_K / FCS_SPLIT, NKS = KHALF / 32;           // 180 k-steps of 32
+    const int rows_here = min(max_rows - row0, 32);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char *>(reinterpret_cast<const unsigned char *>(a) + (size_t)row0 * FCS_ROW_BYTES), 0,
+        rows_here * FCS_ROW_BYTES, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(wph), 0, FCS_K * FCS_N * 2, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(wpl), 0, FCS_K * FCS_N * 2, 0x00027000);
+    // activation fragment of k-step K (global index, 32 k = a quarter of a cell's 128 channels), k-group g: byte
+    // (K >> 2) * 512 + (K & 3) * 64 + g * 16 of the row (hi; the lo halves 256 bytes further)
+    int aoff[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) aoff[t] = (min(row0 + 16 * t + m, max_rows - 1) - row0) * FCS_ROW_BYTES + g * 16;
+    auto a_bytes = [&](int K) __attribute__((always_inline)) { return (K >> 2) * 512 + (K & 3) * 64; };
+    // weight piece of k-step K, column tile u: ((4 K + g) * 1024 + n) * 16 bytes, n = 32 ct + 16 u + m
+    const int woff = (g * FCS_N + ct * 32 + m) * 16;
+    constexpr int WKS = 4 * FCS_N * 16;
+    const int k0 = ksp * NKS;
+    u32x4 xh[DEPTH][2], xl[DEPTH][2], wh[DEPTH][2], wl[DEPTH][2];
+    auto load_step = [&](int slot, int K) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            xh[slot][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff[t], a_bytes(K), 0);
+            xl[slot][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff[t] + 256, a_bytes(K), 0);
+            wh[slot][t] = __builtin_amdgcn_raw_buffer_load_b128(rwh, woff + t * 256, K * WKS, 0);
+            wl[slot][t] = __builtin_amdgcn_raw_buffer_load_b128(rwl, woff + t * 256, K * WKS, 0);
+        }
+    };
+    static_for<DEPTH - 1>([&](auto Jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(Jc)::value;
+        load_step(j, k0 + j);
+    });
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    static_assert(NKS % DEPTH == 0, "the k loop is unrolled by the ring depth");
+    for (int kb = 0; kb < NKS; kb += DEPTH) {
+        static_for<DEPTH>([&](auto Jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(Jc)::value;
+            constexpr int fill = (j + DEPTH - 1) % DEPTH;
+            int kn = kb + j + DEPTH - 1;
+            kn = k0 + (kn < NKS ? kn : NKS - 1);                         // past the end: read again, never used
+            load_step(fill, kn);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_half8(xh[j][t]), as_half8(wl[j][u]), acc[t][u], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_half8(xl[j][t]), as_half8(wh[j][u]), acc[t][u], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_half8(xh[j][t]), as_half8(wh[j][u]), acc[t][u], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    const int pair = rt * 32 + ct;
+    unsigned ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(fin.ticket + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+    fc16_finish<2, 2, 1>(acc, fin, a_inv_scale, sc->inv_swf, ticket, pair, (size_t)pair * 1024, row0, count, max_rows, ct * 32, 0, lane);
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[2] = __builtin_readcyclecounter(); clk[3] = wall_clock64(); }
+}
+
 // The heads from the linear layer's per-tile partial sums (heads_math.h: heads_z_from_q), then log-softmax, tanh and
 // the legal-move mask.  One wave per row.  The search itself does not launch this kernel (the tree step finishes its
 // own leaf from the same sums); it serves nnb_net_forward and the checks.
@@ -1294,6 +1686,9 @@ static inline int cdiv_sp(int a, int b) { return (a + b - 1) / b; }
 #ifndef NNB_FC_SMALL_ROWS
 #define NNB_FC_SMALL_ROWS 256
 #endif
+#ifndef NNB_FC16
+#define NNB_FC16 1          // the linear layer on 16x16x32 tiles (fc16_kernel, fc16_small_kernel); 0: on 32x32x16 tiles
+#endif                      // (fc_split_kernel, fc_split_small_kernel: kept for the A/B, tools/build_variants.py fc32)
 constexpr int kSplitSmallFc = NNB_FC_SMALL_ROWS;
 static_assert(2 * conv_board_lds_bytes() <= 160 * 1024, "two blocks of the convolution kernel share a CU");
 
@@ -1375,13 +1770,21 @@ void launch_net_stage_split(hipStream_t st, int stage, const NetWeights &w, cons
         const FcFinish fin = {w.fc_b, w.heads_w, b.fcq, b.write_hidden ? b.fc : nullptr, b.fchand, b.fcsync, b.fcsync + b.fc_pairs,
                               b.sync_err, b.heads_all};
         if (n_max <= kSplitSmallFc) {                            // one wave per 32 rows x 32 columns x K half
+#if NNB_FC16
+            fc16_small_kernel<NNB_FC_SMALL_DEPTH / 2><<<64 * cdiv_sp(n_max, 32), 64, 0, st>>>(
+#else
             fc_split_small_kernel<NNB_FC_SMALL_DEPTH><<<64 * cdiv_sp(n_max, 32), 64, 0, st>>>(
+#endif
                 a3, b.act3_inv, (const u32x4 *)w.fc_wh, (const u32x4 *)w.fc_wl, w.sp_scales, fin, count_ptr, n_max,
                 b.max_rows, b.clk ? b.clk + 4 : nullptr);
             break;
         }
         const int groups = cdiv_sp(cdiv_sp(n_max, 128), 32);       // 32 row blocks per group of 256 blocks
+#if NNB_FC16
+        fc16_kernel<FC16_BR><<<256 * groups, 256, 0, st>>>(
+#else
         fc_split_kernel<FCS_BR><<<256 * groups, 256, 0, st>>>(
+#endif
             a3, b.act3_inv, (const u32x4 *)w.fc_wh, (const u32x4 *)w.fc_wl, w.sp_scales, fin, count_ptr, n_max,
             b.max_rows, b.shared_chip, b.clk ? b.clk + 4 : nullptr);
         break;

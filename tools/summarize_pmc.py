@@ -32,7 +32,7 @@ def kernel_class(name: str):
         return "conv2" if any(t in name for t in ("<7, 8", "<7,8", "ILi7ELi8E")) else "conv4"
     if "conv_mid" in name:
         return "conv2" if any(t in name for t in ("<7, 8", "<7,8", "ILi7ELi8E")) else "conv4"
-    if "fc_f16_kernel" in name or "fc_kernel" in name or "fc_split_kernel" in name: return "fc"
+    if "fc_f16_kernel" in name or "fc_kernel" in name or "fc_split_kernel" in name or "fc16_kernel" in name: return "fc"
     if "heads" in name: return "heads"
     return None
 

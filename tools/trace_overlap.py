@@ -7,7 +7,7 @@ ev = []
 for f in files:
     for row in csv.DictReader(open(f)):
         n = row["Kernel_Name"]
-        cls = "tree" if "tree_step" in n else "conv" if "conv_pair" in n or "conv_rows" in n or "conv_board" in n else "fc" if "fc_split" in n else None
+        cls = "tree" if "tree_step" in n else "conv" if "conv_pair" in n or "conv_rows" in n or "conv_board" in n else "fc" if "fc_split" in n or "fc16_" in n else None
         if cls:
             ev.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), cls))
 ev.sort()
