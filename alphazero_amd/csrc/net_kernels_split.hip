@@ -1477,6 +1477,13 @@ __device__ __forceinline__ void fc16_tile(const u32x4 *__restrict__ a, const flo
                 static_for<RT>([&](auto T) __attribute__((always_inline)) {
                     constexpr int t = decltype(T)::value;
                     constexpr int cur = (J * RT + t) % NSETS, nxt = (J * RT + t + AHEAD) % NSETS;
+                    const u32x4 xh = fh[cur], xl = fl[cur];
+                    // Per accumulator hi*lo, lo*hi, hi*hi; the four column tiles in between.  A wave issues one
+                    // instruction every four cycles and a matrix instruction holds the pipe for sixteen, so at most
+                    // three other instructions fit between two of them for free: the row tile's memory instructions
+                    // are dealt out behind its three groups of four.
+#pragma unroll
+                    for (int u = 0; u < CT; ++u) NNB_FC16_MFMA(xh, bl[slot][u], acc[t][u]);
                     if constexpr (t + AHEAD < RT) {              // a later row tile's fragments of this k-step
                         fh[nxt] = frag(buf, t + AHEAD, ks, 0);
                         fl[nxt] = frag(buf, t + AHEAD, ks, 1);
@@ -1484,25 +1491,23 @@ __device__ __forceinline__ void fc16_tile(const u32x4 *__restrict__ a, const flo
                         fh[nxt] = frag(nbuf, t + AHEAD - RT, nks, 0);
                         fl[nxt] = frag(nbuf, t + AHEAD - RT, nks, 1);
                     }
-                    const u32x4 xh = fh[cur], xl = fl[cur];
-                    // per accumulator hi*lo, lo*hi, hi*hi; the four column tiles in between
-#pragma unroll
-                    for (int u = 0; u < CT; ++u) NNB_FC16_MFMA(xh, bl[slot][u], acc[t][u]);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < CT; ++u) NNB_FC16_MFMA(xl, bh[slot][u], acc[t][u]);
-#pragma unroll
-                    for (int u = 0; u < CT; ++u) NNB_FC16_MFMA(xh, bh[slot][u], acc[t][u]);
-                    // memory instructions behind every row tile's 12 MFMAs: weights of k-step J + BR - 1 (the ring
-                    // slot's last reader was the previous k-step), column tiles t, t + RT, ...
-#pragma unroll
-                    for (int u = t; u < CT; u += RT) {
-                        bh[fill][u] = load_w(rwh, knext, u);
-                        bl[fill][u] = load_w(rwl, knext, u);
-                    }
                     if constexpr (ks == 0) {                     // slab s+2: registers -> LDS (past the last slab this
                         *reinterpret_cast<u32x4 *>(sdst + ((U + 2) % 3) * FCS_LBUF + t * 16 * FCS_LROW) = stg[set][t];   // rewrites a buffer nobody reads any more)
                     } else {                                     // slab s+4: global -> registers
                         stg[set][t] = load_a(s + 4 < NSLAB ? s + 4 : NSLAB - 1, aoff[t]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < CT; ++u) NNB_FC16_MFMA(xh, bh[slot][u], acc[t][u]);
+                    // weights of k-step J + BR - 1 (the ring slot's last reader was the previous k-step), column tiles
+                    // t, t + RT, ...
+#pragma unroll
+                    for (int u = t; u < CT; u += RT) {
+                        bh[fill][u] = load_w(rwh, knext, u);
+                        bl[fill][u] = load_w(rwl, knext, u);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
