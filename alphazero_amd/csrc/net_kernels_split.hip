@@ -1542,7 +1542,10 @@ __global__ __launch_bounds__(256, 1) void fc16_kernel(const u32x4 *__restrict__ 
     const int count = batch_count_sp(count_ptr, n_fixed);
     int mblocks = gridDim.x >> 3;                            // row blocks the grid provides (8 column/K blocks each)
     int mbx = 4;
-    if (shared_chip && gridDim.x == 256 && count > 1024 && count <= 2048) {   // as fc_split_kernel
+#ifndef NNB_FC_HALF_GRID
+#define NNB_FC_HALF_GRID 1
+#endif
+    if (NNB_FC_HALF_GRID && shared_chip && gridDim.x == 256 && count > 1024 && count <= 2048) {   // as fc_split_kernel
         if (blockIdx.x >= 128) return;
         mblocks = 16;
         mbx = 2;

@@ -27,6 +27,7 @@ VARIANTS = {
     "look128": ["-DNNB_LOOK_ROUNDS=128"],
     "look256": ["-DNNB_LOOK_ROUNDS=256"],
     "fc32": ["-DNNB_FC16=0"],
+    "fullgrid": ["-DNNB_FC_HALF_GRID=0"],
     "lds3": ["-DNNB_FUSED_LDS_KB=3"],
     "lds5": ["-DNNB_FUSED_LDS_KB=5"],
     "lds7": ["-DNNB_FUSED_LDS_KB=7"],
@@ -41,7 +42,7 @@ VARIANTS = {
 AFFECTED = {"NNB_TERMINAL_SIMS_PER_STEP": ["tree_kernels.hip"], "NNB_LOOK_ROUNDS": ["nnb_api.hip"],
             "NNB_STREAM_PROBE": ["nnb_api.hip"], "NNB_FC_SMALL_ROWS": ["net_kernels_split.hip"],
             "NNB_FC_SMALL_DEPTH": ["net_kernels_split.hip"], "NNB_FUSED_LDS_KB": ["nnb_api.hip"],
-            "NNB_FC16": ["net_kernels_split.hip"]}
+            "NNB_FC16": ["net_kernels_split.hip"], "NNB_FC_HALF_GRID": ["net_kernels_split.hip"]}
 
 
 def main():

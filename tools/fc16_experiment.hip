@@ -1,4 +1,4 @@
-// Experiment (not part of the product; included by tools/split_bench.hip): the split linear layer's main loop on
+// The prototype behind fc16_kernel (not part of the product; included by tools/split_bench.hip): the split linear layer's main loop on
 // v_mfma_f32_16x16x32_f16 instead of 32x32x16, to time it.  Same block tile (128 rows x 256 columns x one K half),
 // same LDS slab layout and weight layout, same number of fragment reads, weight loads and matrix cycles per k:
 //   wave w owns columns 64w .. 64w+63 as FOUR 16-column tiles and the block's rows as EIGHT 16-row tiles;

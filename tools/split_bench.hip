@@ -183,6 +183,17 @@ int main(int argc, char **argv) {
             printf("linear 11520->1024 main loop on 16x16x32, %4d rows, ring %d: %8.1f us  %7.1f TFLOP/s  block %llu cycles, clock %.0f MHz\n", n, BR, t,
                    (double)n * 2 * 11520 * 1024 / (t * 1e-6) / 1e12, h[3] - h[0], (double)(h[3] - h[0]) / (double)(h[6] - h[5]) * 100.0);
         };
+        auto fc16_product = [&](int rows) {          // the product's linear layer (fc16_kernel), epilogue and hand-off included
+            float t = time_it([&] {
+                int groups = cdiv_sp(cdiv_sp(rows, 128), 32);
+                fc16_kernel<FC16_BR><<<256 * groups, 256, 0, 0>>>(a3, inv, wfh, wfl, sc, fin, nullptr, rows, n, 0, nullptr);
+            });
+            unsigned long long h[8]; CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sp_clk), sizeof h));
+            printf("linear 11520->1024 on 16x16x32 (fc16_kernel), %4d rows: %8.1f us  %7.1f TFLOP/s  block %llu cycles, clock %.0f MHz\n", rows, t,
+                   (double)rows * 2 * 11520 * 1024 / (t * 1e-6) / 1e12, h[3] - h[0], (double)(h[3] - h[0]) / (double)(h[6] - h[5]) * 100.0);
+        };
+        fc16_product(n);
+        fc16_product(n / 2);
         fc16_run(std::integral_constant<int, 3>{});
         fc16_run(std::integral_constant<int, 4>{});
         fc_run(std::integral_constant<int, 6>{}, I0{}, n);
