@@ -7,7 +7,8 @@
 // (so hi never overflows and lo stays a normal half for everything within 2^-17 of the maximum).
 // hi + lo reproduces x*s to 2^-22 relative (float32 keeps 2^-24), and a product becomes three MFMAs
 //     a*w*(sa*sw) ~= ah*wh + ah*wl + al*wh          (al*wl, 2^-22 of the product, is dropped)
-// on v_mfma_f32_32x32x16_f16 with float32 accumulation; the epilogue multiplies by 1/(sa*sw), exactly.
+// on v_mfma_f32_16x16x32_f16 (the 2->128 layer: 32x32x16) with float32 accumulation; the epilogue multiplies by
+// 1/(sa*sw), exactly.
 // Weights get one scale per layer at load time.  Activations get one scale PER BOARD, taken from that
 // board's own maximum by the kernel that produces them, so a position's outputs do not depend on what
 // else is in the batch.  Bias, ReLU, the heads, log-softmax and tanh are float32 as in the other paths.
