@@ -164,6 +164,12 @@ def main():
                     help="keep all games in one tree step -> forward pass chain instead of two halves on two streams")
     args = ap.parse_args()
 
+    # NNB_BENCH_WATCHDOG_S=N: a rank that has not finished after N seconds dumps every thread's Python stack to stderr and
+    # exits (rehearsals and debugging: a stalled rank otherwise hangs its launcher without a word)
+    if os.environ.get("NNB_BENCH_WATCHDOG_S"):
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["NNB_BENCH_WATCHDOG_S"]), exit=True)
+
     import torch
     import torch.distributed as dist
     from alphazero_amd.engine import TRAJECTORY_BYTES, Engine
