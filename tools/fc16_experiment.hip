@@ -7,7 +7,9 @@
 // The epilogue only keeps the accumulators alive (a sum per lane to memory): the timing is that of the main loop.
 namespace nnb {
 
-template <int BR>
+// ABL (ablations, timing only): 1 no activation loads, 2 no weight loads, 4 no LDS staging writes, 8 no fragment
+// reads, 16 no barrier per slab.
+template <int BR, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void fc16_proto_kernel(const u32x4 *__restrict__ a, const u32x4 *__restrict__ wph,
                                                             const u32x4 *__restrict__ wpl, float *__restrict__ sink,
                                                             int count, int max_rows) {
@@ -117,12 +119,14 @@ __global__ __launch_bounds__(256, 1) void fc16_proto_kernel(const u32x4 *__restr
                 static_for<RT>([&](auto T) __attribute__((always_inline)) {
                     constexpr int t = decltype(T)::value;
                     constexpr int cur = (J * RT + t) % NSETS, nxt = (J * RT + t + AHEAD) % NSETS;
+                    if constexpr (!(ABL & 8)) {
                     if constexpr (t + AHEAD < RT) {              // a later row tile's fragments of this k-step
                         fh[nxt] = frag(buf, t + AHEAD, ks, 0);
                         fl[nxt] = frag(buf, t + AHEAD, ks, 1);
                     } else {                                     // the first row tiles of the next k-step (after the last: read, never used)
                         fh[nxt] = frag(nbuf, t + AHEAD - RT, nks, 0);
                         fl[nxt] = frag(nbuf, t + AHEAD - RT, nks, 1);
+                    }
                     }
                     const u32x4 xh = fh[cur], xl = fl[cur];
                     // per accumulator hi*lo, lo*hi, hi*hi; the four column tiles in between, so that no instruction
@@ -137,19 +141,20 @@ __global__ __launch_bounds__(256, 1) void fc16_proto_kernel(const u32x4 *__restr
 #pragma unroll
                     for (int u = 0; u < CT; ++u) FC16_MFMA(xh, bh[slot][u], acc[t][u]);
                     // memory instructions behind every row tile's 12 MFMAs
-                    if constexpr (t >= CT) {                     // weights of k-step J + BR - 1, column tile t - CT (the
+                    if constexpr (t >= CT && !(ABL & 2)) {       // weights of k-step J + BR - 1, column tile t - CT (the
                         bh[fill][t - CT] = load_w(rwh, knext, t - CT);   // ring slot's last reader was the previous k-step)
                         bl[fill][t - CT] = load_w(rwl, knext, t - CT);
                     }
                     if constexpr (ks == 0) {                     // slab s+2: registers -> LDS
-                        *reinterpret_cast<u32x4 *>(sdst + ((U + 2) % 3) * FCS_LBUF + t * 16 * FCS_LROW) = stg[set][t];
+                        if constexpr (!(ABL & 4))
+                            *reinterpret_cast<u32x4 *>(sdst + ((U + 2) % 3) * FCS_LBUF + t * 16 * FCS_LROW) = stg[set][t];
                     } else {                                     // slab s+4: global -> registers
-                        stg[set][t] = load_a(s + 4 < NSLAB ? s + 4 : NSLAB - 1, aoff[t]);
+                        if constexpr (!(ABL & 1)) stg[set][t] = load_a(s + 4 < NSLAB ? s + 4 : NSLAB - 1, aoff[t]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
             });
-            __syncthreads();
+            if constexpr (!(ABL & 16)) __syncthreads();
         });
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last matrix instructions have left the pipe

@@ -173,14 +173,14 @@ int main(int argc, char **argv) {
     fc_run(std::integral_constant<int, 8>{}, std::integral_constant<int, 15>{}, n);
     {   // the linear layer's main loop on 16x16x32 tiles (tools/fc16_experiment.hip): timing only
         float *sink; CK(hipMalloc((void **)&sink, (size_t)1024 * 256 * 4));
-        auto fc16_run = [&](auto BRc) {
-            constexpr int BR = decltype(BRc)::value;
+        auto fc16_run = [&](auto BRc, auto ABLc) {
+            constexpr int BR = decltype(BRc)::value, ABL = decltype(ABLc)::value;
             float t = time_it([&] {
                 int groups = cdiv_sp(cdiv_sp(n, 128), 32);
-                fc16_proto_kernel<BR><<<256 * groups, 256, 0, 0>>>(a3, wfh, wfl, sink, n, n);
+                fc16_proto_kernel<BR, ABL><<<256 * groups, 256, 0, 0>>>(a3, wfh, wfl, sink, n, n);
             });
             unsigned long long h[8]; CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sp_clk), sizeof h));
-            printf("linear 11520->1024 main loop on 16x16x32, %4d rows, ring %d: %8.1f us  %7.1f TFLOP/s  block %llu cycles, clock %.0f MHz\n", n, BR, t,
+            printf("linear 11520->1024 main loop on 16x16x32, %4d rows, ring %d, ablate %2d: %8.1f us  %7.1f TFLOP/s  block %llu cycles, clock %.0f MHz\n", n, BR, ABL, t,
                    (double)n * 2 * 11520 * 1024 / (t * 1e-6) / 1e12, h[3] - h[0], (double)(h[3] - h[0]) / (double)(h[6] - h[5]) * 100.0);
         };
         auto fc16_product = [&](int rows) {          // the product's linear layer (fc16_kernel), epilogue and hand-off included
@@ -194,10 +194,16 @@ int main(int argc, char **argv) {
         };
         fc16_product(n);
         fc16_product(n / 2);
-        fc16_run(std::integral_constant<int, 3>{});
-        fc16_run(std::integral_constant<int, 4>{});
+        fc16_run(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
+        fc16_run(std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{});
+        fc16_run(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
+        fc16_run(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+        fc16_run(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{});
+        fc16_run(std::integral_constant<int, 3>{}, std::integral_constant<int, 8>{});
+        fc16_run(std::integral_constant<int, 3>{}, std::integral_constant<int, 16>{});
+        fc16_run(std::integral_constant<int, 3>{}, std::integral_constant<int, 31>{});
         fc_run(std::integral_constant<int, 6>{}, I0{}, n);
-        fc16_run(std::integral_constant<int, 3>{});
+        fc16_run(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
     }
     fc_run(std::integral_constant<int, 6>{}, I0{}, n / 2);
     fc_run(std::integral_constant<int, 6>{}, I0{}, n);
