@@ -99,6 +99,27 @@ def test_small_batch_and_large_batch_kernels_agree_bit_for_bit(rp, precision):
         eng.close()
 
 
+@pytest.mark.parametrize("rows", [1500, 2500, 3500])
+def test_every_row_tile_count_of_the_linear_layer_agrees_with_the_small_form(rp, rows):
+    """The large form of the float32-faithful linear layer gives a block 32, 64, 96 or 128 rows depending on the batch
+    (1500, 2500 and 3500 rows take 64, 96 and 128; 400 rows, in the test above, 32), each a different instantiation of
+    its loop.  The same 200 positions, repeated to fill the batch, must come out as the small form evaluates them."""
+    import torch
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.selfplay import random_openings
+    eng = Engine(max_games=rows, max_sims=2, precision="f32s")
+    try:
+        eng.load_state_dict(rp.seeded_state_dict(0), 0)
+        sb, sp = random_openings(eng, 200, 6, seed=21)
+        side200 = np.where(sp[:, None] == 1, sb, sb[:, ::-1]).astype(np.uint64)
+        small_logp, small_value, _ = eng.net_forward(side200)       # 200 rows: one wave per linear-layer block
+        logp, value, _ = eng.net_forward(side200[np.arange(rows) % 200])
+        idx = torch.arange(rows, device=logp.device) % 200
+        assert torch.equal(logp, small_logp[idx]) and torch.equal(value, small_value[idx])
+    finally:
+        eng.close()
+
+
 def test_rows_beyond_four_gigabytes_of_activations(rp):
     """One activation row of the float32-faithful linear layer is 46 080 bytes, so from row 93 207 on a row's byte
     offset no longer fits 32 bits.  The kernels address a row block through a 64-bit base: positions evaluated in the
