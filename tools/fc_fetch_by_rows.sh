@@ -14,7 +14,7 @@ for n in 512 1024 2048 4096; do
 import csv, glob, sys
 d, n = sys.argv[1], int(sys.argv[2])
 vals = [float(r["Counter_Value"]) for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True)
-        for r in csv.DictReader(open(f)) if r["Counter_Name"] == "FETCH_SIZE" and "fc_split_kernel" in r["Kernel_Name"]]
+        for r in csv.DictReader(open(f)) if r["Counter_Name"] == "FETCH_SIZE" and ("fc_split_kernel" in r["Kernel_Name"] or "fc16_kernel" in r["Kernel_Name"])]
 act, w = n * 46080 / 1e6, 47.2
 t = (n + 1023) // 1024
 row_blocks = (n + 32 * t - 1) // (32 * t)
